@@ -1,0 +1,48 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Returns (cfg, views(np), cond_flags, expected outputs(np), raw npz dict)."""
+    from hunyuanworld_mirror_amd.config import WMConfig
+    z = dict(np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False))
+    d = json.loads(str(z["cfg_json"]))
+    d["intermediate_idxs"] = tuple(d["intermediate_idxs"])
+    d["dpt_out_channels"] = tuple(d["dpt_out_channels"])
+    cfg = WMConfig(**d)
+    views = {k[3:]: v for k, v in z.items() if k.startswith("in_")}
+    outs = {k[4:]: v for k, v in z.items() if k.startswith("out_")}
+    return cfg, views, [int(x) for x in z["cond_flags"]], outs, z
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+_WCACHE = {}
+
+
+def torch_weights(cfg):
+    """Synthetic name-keyed weights as torch fp32 tensors (cached per config)."""
+    import torch
+    from hunyuanworld_mirror_amd.weights import iter_params
+    key = json.dumps(cfg.to_dict(), sort_keys=True)
+    if key not in _WCACHE:
+        _WCACHE.clear()
+        _WCACHE[key] = {k: torch.from_numpy(v) for k, v in iter_params(cfg)}
+    return _WCACHE[key]
