@@ -1,2 +1,3 @@
-"""MI355X-native WorldMirror forward pass (HIP kernels behind a C ABI)."""
+"""MI355X-native WorldMirror forward pass (hand-written HIP kernels behind a C ABI)."""
 from .config import WMConfig, param_spec  # noqa: F401
+from .worldmirror import WorldMirror, extract_priors  # noqa: F401

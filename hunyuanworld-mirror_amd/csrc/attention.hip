@@ -1,0 +1,246 @@
+// Flash-attention forward, head_dim 64, 16-bit operands, fp32 online softmax — gfx950.
+//
+// Replaces F.scaled_dot_product_attention at src/models/layers/attention.py:59 for all three users:
+// DINO blocks (L=1374), frame blocks (L=1376) and the cross-view global blocks (L = N*1376).
+//
+// Layout: Q,K,V are [H][rows][64] (head-major; produced by the QKV epilogue kernel), so frame and
+// global attention share one buffer: a "sequence" is a contiguous row range.  O is token-major
+// [rows][H*64], i.e. directly the A operand of the projection GEMM.  For the view-sharded multi-GPU
+// path K/V may be `kv_chunks` gathered shards; softmax is permutation-invariant over keys, so the
+// all-gather's natural [rank][H][rows][64] order is consumed as is.
+//
+// Structure (per guides' "Fused attention prefill" recipe, adapted to D=64): one wave owns 32 query
+// rows with Q fragments in registers; S^T = K Q^T is computed with K as the MFMA A operand so every
+// lane holds one query row's scores (row max/sum need a single permlane32 swap); the S^T accumulator
+// is fed straight back as the B operand of O^T += V^T P^T; V^T fragments come from
+// ds_read_b64_tr_b16 on a [4 keys][32 d] blocked image (each 256-B block covers all 64 banks);
+// K rows are XOR-swizzled for conflict-free ds_read_b128; K/V tiles are register-staged and double
+// buffered (global loads issued before the MFMA phase, LDS writes after it).
+#include "wm_common.h"
+#include "wm_kernels.h"
+
+namespace {
+
+constexpr int KVB = 64;                 // keys per tile
+constexpr int TILE_B = KVB * 64 * 2;    // 8 KiB per K or V tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
+
+__device__ __forceinline__ uint32_t pack2(float a, float b, int T) {
+  return T == WM_T_BF16 ? ((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16)) : ((uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16));
+}
+
+template <int T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int QT = NW * 32;
+  constexpr int CPT = 512 / NT;  // 16-B chunks per thread per tile (K and V each)
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K|V]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, ql = lane & 31;
+  const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
+  const int nseq = p.q_rows / p.seq_len;
+  const int tiles_per_head = tiles_per_seq * nseq;
+  const int lid = xcd_remap(blockIdx.x, tiles_per_head * p.H);
+  const int head = lid / tiles_per_head;
+  const int tile = lid - head * tiles_per_head;
+  const int seq = tile / tiles_per_seq;
+  const int qt = tile - seq * tiles_per_seq;
+  const int seq_row0 = seq * p.seq_len;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q=ql, h) holds Q[q][16ks + 8h + j]
+  const u16* Qh = (const u16*)p.Q + (size_t)head * p.q_head_stride * 64;
+  int qrow_l = qt * QT + wave * 32 + ql;              // row within the sequence
+  const bool q_valid = qrow_l < p.seq_len;
+  qrow_l = q_valid ? qrow_l : p.seq_len - 1;
+  const u16* qptr = Qh + (size_t)(seq_row0 + qrow_l) * 64;
+  s16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const s16x8*)(qptr + ks * 16 + h * 8);
+
+  // ---- K/V segments
+  const int seg_rows = p.kv_chunks > 1 ? p.kv_rows_per_chunk : p.seq_len;
+  const int seg_off = p.kv_chunks > 1 ? 0 : seq_row0;
+  const int ntpc = (seg_rows + KVB - 1) / KVB;
+  const int ntiles = ntpc * p.kv_chunks;
+  const u16* Kb = (const u16*)p.K + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
+  const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
+
+  uint4 kreg[CPT], vreg[CPT];
+  auto load_tile = [&](int t) {
+    const int c = t / ntpc, j = t - c * ntpc;
+    const u16* kp = Kb + (size_t)c * p.kv_chunk_stride;
+    const u16* vp = Vb + (size_t)c * p.kv_chunk_stride;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int ch = tid + i * NT, key = ch >> 3, d8 = ch & 7;
+      const int krow = j * KVB + key;
+      if (krow < seg_rows) {
+        kreg[i] = *(const uint4*)(kp + (size_t)krow * 64 + d8 * 8);
+        vreg[i] = *(const uint4*)(vp + (size_t)krow * 64 + d8 * 8);
+      } else {
+        kreg[i] = make_uint4(0, 0, 0, 0);
+        vreg[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* kt = smem + buf * 2 * TILE_B;
+    char* vt = kt + TILE_B;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int ch = tid + i * NT, key = ch >> 3, d8 = ch & 7;
+      *(uint4*)(kt + key * 128 + ((d8 ^ ((key >> 1) & 7)) << 4)) = kreg[i];
+      *(uint4*)(vt + (((key >> 2) * 2 + (d8 >> 2)) << 8) + ((key & 3) << 6) + ((d8 & 3) << 4)) = vreg[i];
+    }
+  };
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  // per-lane constant part of the transposed V read address (see header)
+  const int vtr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const char* kt = smem + cur * 2 * TILE_B;
+    const char* vt = kt + TILE_B;
+    if (t + 1 < ntiles) load_tile(t + 1);  // global -> regs, hidden under the MFMA phase
+
+    // ---- S^T = K Q^T : st[kt][r] = S[key = 32kt + (r&3)+8(r>>2)+4h][q = ql]
+    f32x16 st[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[k2][r] = 0.f;
+      const int key = k2 * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const s16x8 kf = *(const s16x8*)(kt + key * 128 + (((2 * ks + h) ^ ((key >> 1) & 7)) << 4));
+        st[k2] = mfma32<T>(kf, qf[ks], st[k2]);
+      }
+    }
+    // ---- tail mask (wave-uniform branch; only the last tile of a segment)
+    {
+      const int j = t % ntpc;
+      const int valid = seg_rows - j * KVB;
+      if (valid < KVB) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key >= valid) st[k2][r] = -INFINITY;
+          }
+      }
+    }
+    // ---- online softmax (scores already carry 1/sqrt(d): q was pre-scaled)
+    float mloc = st[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);
+    {
+      const uint32_t mb = __builtin_bit_cast(uint32_t, mloc);
+      auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+      mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
+    if (!__all(mloc <= m_run)) {  // wave-uniform: rescale only when some row's max grew
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+    }
+    const float mc = -m_run * LOG2E;
+    s16x8 pf[2][2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[k2][r], LOG2E, mc));
+        l_run += pv[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 u;
+        u.x = pack2(pv[8 * s2 + 0], pv[8 * s2 + 1], T);
+        u.y = pack2(pv[8 * s2 + 2], pv[8 * s2 + 3], T);
+        u.z = pack2(pv[8 * s2 + 4], pv[8 * s2 + 5], T);
+        u.w = pack2(pv[8 * s2 + 6], pv[8 * s2 + 7], T);
+        pf[k2][s2] = __builtin_bit_cast(s16x8, u);
+      }
+    }
+    // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads, B = P^T (the S^T accumulator)
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int key0 = k2 * 32 + s2 * 16 + 4 * h;  // elements 0-3: key0..key0+3 ; 4-7: key0+8..key0+11
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const char* b0 = vt + (((key0 >> 2) * 2 + d) << 8) + vtr_lane;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(b0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(b0 + 2 * 2 * 256));
+          s16x8 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+          ot[d] = mfma32<T>(vf, pf[k2][s2], ot[d]);
+        }
+      }
+    if (t + 1 < ntiles) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][head*64 + d] = O^T / l
+  {
+    const uint32_t lb = __builtin_bit_cast(uint32_t, l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
+    const float l = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+    const float inv = 1.0f / l;
+    if (q_valid) {
+      u16* op = (u16*)p.O + ((size_t)(seq_row0 + qrow_l) * p.H + head) * 64;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 u;
+          u.x = pack2(ot[d][4 * g + 0] * inv, ot[d][4 * g + 1] * inv, T);
+          u.y = pack2(ot[d][4 * g + 2] * inv, ot[d][4 * g + 3] * inv, T);
+          *(uint2*)(op + 32 * d + 8 * g + 4 * h) = u;
+        }
+    }
+  }
+}
+
+template <int T, int NW>
+hipError_t launch(const WmAttnArgs& a, hipStream_t s) {
+  constexpr int QT = NW * 32;
+  const int tiles_per_seq = (a.seq_len + QT - 1) / QT;
+  const int nseq = a.q_rows / a.seq_len;
+  dim3 grid(tiles_per_seq * nseq * a.H), block(NW * 64);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NW>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
+  if (a.q_rows <= 0) return hipSuccess;
+  if (a.seq_len <= 0 || a.q_rows % a.seq_len != 0 || a.kv_chunks < 1) return hipErrorInvalidValue;
+  return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4>(a, s) : launch<WM_T_F16, 4>(a, s);
+}

@@ -1,0 +1,376 @@
+// HBM-bound kernels of the WorldMirror path: LayerNorm, QKV post-processing (per-head LayerNorm +
+// 2-D RoPE + head-major relayout), patchify im2col, token assembly, bilinear resize, DPT tail.
+// All are vectorised 16 B/lane where the layout allows and sized to ~8 blocks/CU (guides §6 G11/G13).
+#include "wm_common.h"
+#include "wm_kernels.h"
+
+namespace {
+
+constexpr float RESNET_MEAN[3] = {0.485f, 0.456f, 0.406f};  // visual_transformer.py:16-17
+constexpr float RESNET_STD[3] = {0.229f, 0.224f, 0.225f};
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row, row cached in registers (D <= 2048), two-pass mean/variance like torch.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const WmLnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nrows = (long long)p.groups * p.rows_per_group;
+  if (row >= nrows) return;
+  const int g = (int)(row / p.rows_per_group), q = (int)(row - (long long)g * p.rows_per_group);
+  const float* x = p.x + ((size_t)g * p.in_group + p.in_off + q) * p.ld_in;
+  const size_t orow = (size_t)g * p.out_group + p.out_off + q;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = c < p.D ? *(const float4*)(x + c) : make_float4(0, 0, 0, 0);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) / p.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < p.D) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      ss += a * a + b * b + cc * cc + d * d;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / p.D + p.eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= p.D) continue;
+    float4 w = p.w ? *(const float4*)(p.w + c) : make_float4(1, 1, 1, 1);
+    float4 b = p.b ? *(const float4*)(p.b + c) : make_float4(0, 0, 0, 0);
+    float4 y;
+    y.x = (v[i].x - mean) * rstd * w.x + b.x;
+    y.y = (v[i].y - mean) * rstd * w.y + b.y;
+    y.z = (v[i].z - mean) * rstd * w.z + b.z;
+    y.w = (v[i].w - mean) * rstd * w.w + b.w;
+    if (p.out_f32) {
+      *(float4*)((float*)p.y + orow * p.ld_out + c) = y;
+    } else {
+      uint2 u;
+      if (p.dtype == WM_T_BF16) {
+        u.x = (uint32_t)f2bf(y.x) | ((uint32_t)f2bf(y.y) << 16);
+        u.y = (uint32_t)f2bf(y.z) | ((uint32_t)f2bf(y.w) << 16);
+      } else {
+        u.x = (uint32_t)f2h(y.x) | ((uint32_t)f2h(y.y) << 16);
+        u.y = (uint32_t)f2h(y.z) | ((uint32_t)f2h(y.w) << 16);
+      }
+      *(uint2*)((u16*)p.y + orow * p.ld_out + c) = u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ QKV post
+// One wave = one token x 4 heads; 16 lanes per head vector (4 elements per lane).
+// attention.py:50-56: split heads, q/k LayerNorm(64, eps 1e-5, affine), 2-D RoPE (rope.py:148-181).
+template <int T>
+__global__ __launch_bounds__(256) void qkv_post_kernel(const WmQkvArgs p) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, hg = lane >> 4;
+  const int hgroups = p.H >> 2;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long long)p.M * hgroups) return;
+  const int m = (int)(wid / hgroups);
+  const int head = ((int)(wid - (long long)m * hgroups) << 2) + hg;
+  const int D = p.H * 64;
+  const float* row = p.qkv + (size_t)m * 3 * D + head * 64 + sub * 4;
+
+  // rotary angles for this token (specials sit at (0,0): identity)
+  float c[4] = {1, 1, 1, 1}, s[4] = {0, 0, 0, 0};
+  if (p.rope_cos) {
+    const int t = m % p.tokens_per_view;
+    int pos = 0;
+    if (t >= p.patch_start) {
+      const int idx = t - p.patch_start;
+      const int y = idx / p.grid_w + 1, x = idx - (y - 1) * p.grid_w + 1;
+      pos = sub < 8 ? y : x;  // elements 0..31 rotate by y, 32..63 by x
+    }
+    const int f = (sub * 4) & 15;  // frequency index = element % 16
+    const float4 cc = *(const float4*)(p.rope_cos + pos * 16 + f);
+    const float4 sn = *(const float4*)(p.rope_sin + pos * 16 + f);
+    c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+    s[0] = sn.x; s[1] = sn.y; s[2] = sn.z; s[3] = sn.w;
+  }
+  const size_t obase = ((size_t)head * p.head_stride + m) * 64 + sub * 4;
+
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    float4 v4 = *(const float4*)(row + which * D);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    if (which < 2) {
+      const float* nw = which == 0 ? p.qn_w : p.kn_w;
+      const float* nb = which == 0 ? p.qn_b : p.kn_b;
+      if (nw) {
+        float sm = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        const float mean = sm * (1.0f / 64.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float rstd = 1.0f / sqrtf(ss * (1.0f / 64.0f) + 1e-5f);
+        const float4 w4 = *(const float4*)(nw + sub * 4), b4 = *(const float4*)(nb + sub * 4);
+        v[0] = v[0] * rstd * w4.x + b4.x; v[1] = v[1] * rstd * w4.y + b4.y;
+        v[2] = v[2] * rstd * w4.z + b4.z; v[3] = v[3] * rstd * w4.w + b4.w;
+      }
+      if (p.rope_cos) {
+        // partner holds element e^16 (lane sub^4): first half of each 32 gets -x2, second half +x1
+        const float sign = (sub & 4) ? 1.0f : -1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float o = __shfl_xor(v[i], 4);
+          v[i] = v[i] * c[i] + sign * o * s[i];
+        }
+      }
+      if (which == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= p.q_scale;
+      }
+    }
+    uint2 u;
+    u.x = (uint32_t)f2t<T>(v[0]) | ((uint32_t)f2t<T>(v[1]) << 16);
+    u.y = (uint32_t)f2t<T>(v[2]) | ((uint32_t)f2t<T>(v[3]) << 16);
+    u16* dst = (u16*)(which == 0 ? p.q : which == 1 ? p.k : p.v);
+    *(uint2*)(dst + obase) = u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ im2col
+// patch_embed.py:70 conv k=s=ps as GEMM: row (n,py,px), column c*ps*ps + ky*ps + kx, zero-padded to Kpad.
+template <int T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, u16* __restrict__ out, int N, int C,
+                                                     int H, int W, int ps, int Kpad, int normalize) {
+  const int gh = H / ps, gw = W / ps, K = C * ps * ps;
+  const size_t total = (size_t)N * gh * gw * Kpad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % Kpad);
+    const size_t r = i / Kpad;
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (ps * ps), kk = k - c * ps * ps, ky = kk / ps, kx = kk - ky * ps;
+      const int px = (int)(r % gw), py = (int)((r / gw) % gh), n = (int)(r / ((size_t)gw * gh));
+      v = img[(((size_t)n * C + c) * H + py * ps + ky) * W + px * ps + kx];
+      if (normalize) v = (v - RESNET_MEAN[c]) / RESNET_STD[c];
+    }
+    out[i] = f2t<T>(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ tokens
+// vision_transformer.py:215-219: cls + pos[0], then R registers (patch rows are written by the
+// patchify GEMM epilogue with pos[1+j] added).
+__global__ __launch_bounds__(256) void dino_special_kernel(const float* cls, const float* reg, const float* pos, float* X,
+                                                           int N, int T, int R, int D) {
+  const int total = N * (1 + R) * D;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int d = i % D, t = (i / D) % (1 + R), n = i / (D * (1 + R));
+    X[((size_t)n * T + t) * D + d] = t == 0 ? cls[d] + pos[d] : reg[(t - 1) * D + d];
+  }
+}
+
+// visual_transformer.py:285-295,397-416: [cam, reg x R, (pose, ray)] ; token slot 0 for global view 0.
+__global__ __launch_bounds__(256) void vgt_special_kernel(float* X, const float* cam, const float* reg, const float* pose,
+                                                          const float* ray, int N, int P, int R, int D, int cond,
+                                                          int first_view_global) {
+  const int psi = 1 + R + (cond ? 2 : 0);
+  const int total = N * psi * D;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int d = i % D, t = (i / D) % psi, n = i / (D * psi);
+    const int slot = (first_view_global + n) == 0 ? 0 : 1;
+    float v;
+    if (t == 0) v = cam[slot * D + d];
+    else if (t <= R) v = reg[(slot * R + (t - 1)) * D + d];
+    else if (t == R + 1) v = pose ? pose[(size_t)n * D + d] : 0.f;
+    else v = ray ? ray[(size_t)n * D + d] : 0.f;
+    X[((size_t)n * P + t) * D + d] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                                     int cols4, int ld_src, int ld_dst) {
+  const size_t total = (size_t)rows * cols4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / cols4;
+    const int c = (int)(i - r * cols4) * 4;
+    *(float4*)(dst + r * ld_dst + c) = *(const float4*)(src + r * ld_src + c);
+  }
+}
+
+// F.interpolate(mode="bilinear", align_corners=True) on NHWC f32 (dense_head.py:217-225,535)
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int Hi,
+                                                       int Wi, int Ho, int Wo, int C4, const float* __restrict__ addx,
+                                                       const float* __restrict__ addy) {
+  const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int x = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const float fy = sy * y, fx = sx * x;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < Hi - 1 ? y0 : Hi - 1;
+    x0 = x0 < Wi - 1 ? x0 : Wi - 1;
+    const int y1 = y0 < Hi - 1 ? y0 + 1 : y0, x1 = x0 < Wi - 1 ? x0 + 1 : x0;
+    const float wy = fy - y0, wx = fx - x0;
+    const size_t C = (size_t)C4 * 4;
+    const float* b = in + (size_t)n * Hi * Wi * C + c;
+    const float4 v00 = *(const float4*)(b + ((size_t)y0 * Wi + x0) * C);
+    const float4 v01 = *(const float4*)(b + ((size_t)y0 * Wi + x1) * C);
+    const float4 v10 = *(const float4*)(b + ((size_t)y1 * Wi + x0) * C);
+    const float4 v11 = *(const float4*)(b + ((size_t)y1 * Wi + x1) * C);
+    const float w00 = (1.f - wy) * (1.f - wx), w01 = (1.f - wy) * wx, w10 = wy * (1.f - wx), w11 = wy * wx;
+    float4 o;
+    o.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+    o.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+    o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
+    o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+    if (addx) {  // separable UV position embedding: first C/2 channels depend on x, the rest on y
+      const int half = (int)(C >> 1);
+      const float4 a = c < half ? *(const float4*)(addx + (size_t)x * half + c) : *(const float4*)(addy + (size_t)y * half + (c - half));
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    *(float4*)(out + (((size_t)n * Ho + y) * Wo + x) * C + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ o, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i];
+    ((float4*)o)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+// dense_head.py:97-105,297-344: ReLU -> 1x1 conv 32->C -> split (attr C-1, conf) -> activations.
+__global__ __launch_bounds__(256) void dpt_tail_kernel(const float* __restrict__ y32, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ attr,
+                                                       float* __restrict__ conf, size_t npix, int C, int act) {
+  __shared__ float sw[4 * 32 + 4];
+  if (threadIdx.x < C * 32) sw[threadIdx.x] = w[threadIdx.x];
+  if (threadIdx.x < C) sw[128 + threadIdx.x] = b[threadIdx.x];
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+    float o[4] = {sw[128], sw[129], sw[130], sw[131]};
+    const float4* src = (const float4*)(y32 + i * 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float4 v = src[k];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) o[c] += v.x * sw[c * 32 + 4 * k] + v.y * sw[c * 32 + 4 * k + 1] + v.z * sw[c * 32 + 4 * k + 2] + v.w * sw[c * 32 + 4 * k + 3];
+    }
+    const int A = C - 1;
+    if (act == WM_ACT_NORM) {
+      float nn = 0.f;
+      for (int c = 0; c < A; ++c) nn += o[c] * o[c];
+      nn = sqrtf(nn);
+      for (int c = 0; c < A; ++c) attr[i * A + c] = o[c] / nn;
+    } else if (act == WM_ACT_EXP) {
+      for (int c = 0; c < A; ++c) attr[i * A + c] = expf(o[c]);
+    } else {
+      for (int c = 0; c < A; ++c) {
+        const float e = expm1f(fabsf(o[c]));
+        attr[i * A + c] = o[c] > 0.f ? e : (o[c] < 0.f ? -e : 0.f);
+      }
+    }
+    conf[i] = 1.0f + expf(o[A]);
+  }
+}
+
+inline int grid_for(size_t n, int per_block = 256) {
+  size_t g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+hipError_t wm_launch_layernorm(const WmLnArgs& a, hipStream_t s) {
+  const long long rows = (long long)a.groups * a.rows_per_group;
+  if (rows <= 0) return hipSuccess;
+  if (a.D % 4 || a.D > 2048 || a.ld_in % 4 || a.ld_out % 4) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const int nv = (a.D + 255) / 256;
+  if (nv <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, a);
+  else if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, a);
+  else if (nv <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_qkv_post(const WmQkvArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.H % 4) return hipErrorInvalidValue;
+  const long long waves = (long long)a.M * (a.H / 4);
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (a.dtype == WM_T_BF16) hipLaunchKernelGGL(qkv_post_kernel<WM_T_BF16>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(qkv_post_kernel<WM_T_F16>, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_im2col(const float* img, void* out, int N, int C, int H, int W, int ps, int Kpad, int normalize,
+                            int dtype, hipStream_t s) {
+  const size_t total = (size_t)N * (H / ps) * (W / ps) * Kpad;
+  if (!total) return hipSuccess;
+  if (dtype == WM_T_BF16)
+    hipLaunchKernelGGL(im2col_kernel<WM_T_BF16>, dim3(grid_for(total)), dim3(256), 0, s, img, (u16*)out, N, C, H, W, ps, Kpad, normalize);
+  else
+    hipLaunchKernelGGL(im2col_kernel<WM_T_F16>, dim3(grid_for(total)), dim3(256), 0, s, img, (u16*)out, N, C, H, W, ps, Kpad, normalize);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_dino_tokens(const float* /*patch*/, const float* cls, const float* reg, const float* pos, float* X,
+                                 int N, int hw, int R, int D, hipStream_t s) {
+  hipLaunchKernelGGL(dino_special_kernel, dim3(grid_for((size_t)N * (1 + R) * D)), dim3(256), 0, s, cls, reg, pos, X, N,
+                     1 + R + hw, R, D);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_vgt_special(float* X, const float* cam_tok, const float* reg_tok, const float* pose_tok,
+                                 const float* ray_tok, int N, int P, int R, int D, int cond, int first_view_global,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(vgt_special_kernel, dim3(grid_for((size_t)N * (3 + R) * D)), dim3(256), 0, s, X, cam_tok, reg_tok,
+                     pose_tok, ray_tok, N, P, R, D, cond, first_view_global);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_copy2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s) {
+  if (cols % 4 || ld_src % 4 || ld_dst % 4) return hipErrorInvalidValue;
+  if (!rows) return hipSuccess;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((size_t)rows * cols / 4)), dim3(256), 0, s, src, dst, rows, cols / 4, ld_src, ld_dst);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, const float* addx,
+                              const float* addy, hipStream_t s) {
+  if (C % 8) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C / 4, addx, addy);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+  if (n % 4) return hipErrorInvalidValue;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, a, b, out, n / 4);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_dpt_tail(const float* y32, const float* w, const float* b, float* attr, float* conf, size_t npix,
+                              int C, int act, hipStream_t s) {
+  if (C < 2 || C > 4) return hipErrorInvalidValue;
+  if (!npix) return hipSuccess;
+  hipLaunchKernelGGL(dpt_tail_kernel, dim3(grid_for(npix)), dim3(256), 0, s, y32, w, b, attr, conf, npix, C, act);
+  return hipGetLastError();
+}

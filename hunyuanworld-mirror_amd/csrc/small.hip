@@ -1,0 +1,208 @@
+// fp32 kernels for the camera head and the pose/ray prior encoders (M = number of views, tiny).
+//
+// The reference runs the camera head in fp32 (worldmirror.py:146) and camera_params is the most
+// precision-sensitive output, so this path keeps fp32 weights and arithmetic.  With
+// M <= 64 rows these layers are weight-streaming (HBM) bound: 216 M parameters re-read on each of
+// the 4 refinement iterations (camera_head.py:84-102).
+#include "wm_common.h"
+#include "wm_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+constexpr int LBM = 64, LBN = 32, LBK = 64, LPAD = 68;
+
+// Y[M][N] (+)= gamma * post(pre(X) W^T + b)
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                         const float* __restrict__ b, float* __restrict__ Y, int M, int N,
+                                                         int K, int ldx, int ldy, int pre_act, int post_act,
+                                                         const float* __restrict__ gamma, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float xs[LBM * LPAD];
+  __shared__ __attribute__((aligned(16))) float ws[LBN * LPAD];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int n0 = blockIdx.x * LBN, m0 = blockIdx.y * LBM;
+  float acc[4][2] = {};
+  for (int k0 = 0; k0 < K; k0 += LBK) {
+    // X tile 64 x 64: 1024 float4, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + i * 256, r = id >> 4, c = (id & 15) * 4;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (m0 + r < M && k0 + c < K) {
+        const float* s = X + (size_t)(m0 + r) * ldx + k0 + c;
+        if (k0 + c + 3 < K) v = *(const float4*)s;
+        else { v.x = s[0]; if (k0 + c + 1 < K) v.y = s[1]; if (k0 + c + 2 < K) v.z = s[2]; }
+        if (pre_act == 1) { v.x = silu(v.x); v.y = silu(v.y); v.z = silu(v.z); v.w = silu(v.w); }
+      }
+      *(float4*)(xs + r * LPAD + c) = v;
+    }
+    // W tile 32 x 64: 512 float4, 2 per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + i * 256, r = id >> 4, c = (id & 15) * 4;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (n0 + r < N && k0 + c < K) {
+        const float* s = W + (size_t)(n0 + r) * K + k0 + c;
+        if (k0 + c + 3 < K && (K & 3) == 0) v = *(const float4*)s;
+        else { v.x = s[0]; if (k0 + c + 1 < K) v.y = s[1]; if (k0 + c + 2 < K) v.z = s[2]; if (k0 + c + 3 < K) v.w = s[3]; }
+      }
+      *(float4*)(ws + r * LPAD + c) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < LBK; k += 4) {
+      float4 xv[4], wv[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[i] = *(const float4*)(xs + (ty * 4 + i) * LPAD + k);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wv[j] = *(const float4*)(ws + (tx * 2 + j) * LPAD + k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] += xv[i].x * wv[j].x + xv[i].y * wv[j].y + xv[i].z * wv[j].z + xv[i].w * wv[j].w;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 2 + j;
+      if (m >= M || n >= N) continue;
+      float v = acc[i][j] + (b ? b[n] : 0.f);
+      if (post_act == 1) v = silu(v);
+      else if (post_act == 2) v = gelu_erf(v);
+      if (gamma) v *= gamma[n];
+      float* y = Y + (size_t)m * ldy + n;
+      *y = accumulate ? *y + v : v;
+    }
+}
+
+// softmax(q k^T / sqrt(hd)) v over S tokens; one wave per (head, query)
+__global__ __launch_bounds__(64) void small_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S,
+                                                             int heads, int hd) {
+  extern __shared__ float sc[];  // S scores
+  const int lane = threadIdx.x, head = blockIdx.x % heads, i = blockIdx.x / heads;
+  const int D = heads * hd;
+  const float* q = qkv + (size_t)i * 3 * D + head * hd;
+  const float scale = 1.0f / sqrtf((float)hd);
+  float mx = -INFINITY;
+  for (int j = lane; j < S; j += 64) {
+    const float* k = qkv + (size_t)j * 3 * D + D + head * hd;
+    float s = 0.f;
+    for (int d = 0; d < hd; ++d) s += q[d] * scale * k[d];
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < S; j += 64) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  for (int d = lane; d < hd; d += 64) {
+    float o = 0.f;
+    for (int j = 0; j < S; ++j) o += sc[j] * qkv[(size_t)j * 3 * D + 2 * D + head * hd + d];
+    out[(size_t)i * D + head * hd + d] = o / sum;
+  }
+}
+
+// camera_head.py:84-88: h = gate * (LN_noaffine(tok) * (1 + scale) + shift) + tok ; one wave per row
+__global__ __launch_bounds__(64) void adaln_kernel(const float* __restrict__ tok, const float* __restrict__ mod,
+                                                   float* __restrict__ h, int D, float eps) {
+  const int lane = threadIdx.x, row = blockIdx.x;
+  const float* x = tok + (size_t)row * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += x[c];
+  const float mean = wave_sum(s) / D;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) { const float d = x[c] - mean; ss += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / D + eps);
+  const float* m = mod + (size_t)row * 3 * D;
+  for (int c = lane; c < D; c += 64) {
+    const float ln = (x[c] - mean) * rstd;
+    h[(size_t)row * D + c] = m[2 * D + c] * (ln * (1.0f + m[D + c]) + m[c]) + x[c];
+  }
+}
+
+__global__ void cam_update_kernel(float* pred, const float* delta, float* out, int n, int first) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = i / 9, c = i - s * 9;
+  const float v = first ? delta[s * 12 + c] : pred[s * 12 + c] + delta[s * 12 + c];
+  pred[s * 12 + c] = v;
+  out[i] = c >= 7 ? fmaxf(v, 0.f) : v;  // camera_head.py:116-147: t, quat linear; fov ReLU
+}
+
+// camera_utils.py:46-75 + rotation.py:8-38 + worldmirror.py:165-175 (inverse of [R|t;0 0 0 1])
+__global__ void cam_matrices_kernel(const float* __restrict__ p, float* __restrict__ poses, float* __restrict__ intrs,
+                                    int S, int H, int W) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const float* v = p + s * 9;
+  const float i = v[3], j = v[4], k = v[5], r = v[6];
+  const float two_s = 2.0f / (i * i + j * j + k * k + r * r);
+  float R[9] = {1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)};
+  // general 3x3 inverse (the reference calls torch.linalg.inv on the 4x4), then t' = -R^-1 t
+  const float c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+  const float det = R[0] * c00 + R[1] * c01 + R[2] * c02, id = 1.0f / det;
+  float Ri[9] = {c00 * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
+                 c01 * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
+                 c02 * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
+  float* o = poses + s * 16;
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) o[a * 4 + b] = Ri[a * 3 + b];
+    o[a * 4 + 3] = -(Ri[a * 3] * v[0] + Ri[a * 3 + 1] * v[1] + Ri[a * 3 + 2] * v[2]);
+  }
+  o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+  float* K = intrs + s * 9;
+  for (int a = 0; a < 9; ++a) K[a] = 0.f;
+  K[4] = H * 0.5f / tanf(v[7] * 0.5f);
+  K[0] = W * 0.5f / tanf(v[8] * 0.5f);
+  K[2] = W * 0.5f;
+  K[5] = H * 0.5f;
+  K[8] = 1.0f;
+}
+
+}  // namespace
+
+hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int ldx,
+                                int ldy, int pre_act, int post_act, const float* gamma, int accumulate, hipStream_t s) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (ldx % 4) return hipErrorInvalidValue;
+  dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM), block(256);
+  hipLaunchKernelGGL(linear_f32_kernel, grid, block, 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_small_attention(const float* qkv, float* out, int S, int heads, int hd, hipStream_t s) {
+  if (S <= 0) return hipSuccess;
+  if (S > 8192) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(small_attention_kernel, dim3(S * heads), dim3(64), S * sizeof(float), s, qkv, out, S, heads, hd);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_adaln(const float* tok, const float* mod, float* h, int S, int D, float eps, hipStream_t s) {
+  if (S <= 0) return hipSuccess;
+  hipLaunchKernelGGL(adaln_kernel, dim3(S), dim3(64), 0, s, tok, mod, h, D, eps);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_cam_matrices(const float* params, float* poses, float* intrs, int S, int H, int W, hipStream_t s) {
+  if (S <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cam_matrices_kernel, dim3((S + 63) / 64), dim3(64), 0, s, params, poses, intrs, S, H, W);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_cam_update(float* pred, const float* delta, float* out, int S, int first, hipStream_t s) {
+  if (S <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cam_update_kernel, dim3((S * 9 + 255) / 256), dim3(256), 0, s, pred, delta, out, S * 9, first);
+  return hipGetLastError();
+}

@@ -1,0 +1,65 @@
+// Shared device/host helpers for the WorldMirror HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;     // 8 x 16-bit MFMA A/B fragment
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;  // same, typed for the f16 builtin
+typedef __attribute__((ext_vector_type(8))) __bf16 b16x8;    // same, typed for the bf16 builtin
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// 16-bit operand element types understood by the kernels
+enum { WM_T_BF16 = 0, WM_T_F16 = 1 };
+
+__device__ __forceinline__ u16 f2bf(float x) {  // round-to-nearest-even, NaN preserved by the cast
+  __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(u16, b);
+}
+__device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, ((uint32_t)v) << 16); }
+__device__ __forceinline__ u16 f2h(float x) {
+  _Float16 h = (_Float16)x;
+  return __builtin_bit_cast(u16, h);
+}
+__device__ __forceinline__ float h2f(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
+
+template <int T> __device__ __forceinline__ u16 f2t(float x) { return T == WM_T_BF16 ? f2bf(x) : f2h(x); }
+template <int T> __device__ __forceinline__ float t2f(u16 v) { return T == WM_T_BF16 ? bf2f(v) : h2f(v); }
+
+// D(32x32 f32) += A(32x16) * B(16x32); lane l: A[row l&31][k=8(l>>5)+j], B[k=8(l>>5)+j][col l&31];
+// D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5)  (guides/cdna_hip_programming.md §3)
+template <int T>
+__device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
+  if constexpr (T == WM_T_BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// XCD-aware bijective block remap (guides T1): blocks b and b+8 share an XCD; give each XCD a
+// contiguous chunk of the logical tile space so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+#define WM_CHECK_HIP(expr)                                                            \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) return wm_fail(hipGetErrorString(_e), __FILE__, __LINE__);  \
+  } while (0)

@@ -1,0 +1,112 @@
+// Internal launcher interface between the host orchestrator (wm_model.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// ------------------------------------------------------------------ GEMM (gemm.hip)
+enum {
+  WM_EPI_F32 = 0,         // C f32 = acc + bias
+  WM_EPI_T16 = 1,         // C 16-bit = acc + bias
+  WM_EPI_GELU_T16 = 2,    // C 16-bit = gelu_erf(acc + bias)
+  WM_EPI_RESID = 3,       // C f32 += gamma[col] * (acc + bias)           (LayerScale + residual)
+  WM_EPI_ROWMAP_ADD = 4,  // C f32 [row-remapped] (+)= acc + bias + add[row % rpg][col]
+  WM_EPI_CONVT = 5,       // k==stride ConvTranspose2d pixel-shuffle scatter, NHWC f32 out
+};
+
+struct WmGemmArgs {
+  const void* A; const void* W; void* C;
+  const float* bias; const float* gamma; const float* add;
+  int M, N, K, lda, ldw, ldc;
+  int dtype, epi;
+  int rows_per_group, out_group, out_off, accumulate, out16;  // WM_EPI_ROWMAP_ADD (out16: C is 16-bit, no accumulate)
+  int ct_k, ct_cout, ct_gh, ct_gw;                     // WM_EPI_CONVT
+};
+hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ attention (attention.hip)
+struct WmAttnArgs {
+  const void* Q; const void* K; const void* V;  // 16-bit [H][rows][64]; q pre-scaled by 1/8
+  void* O;                                      // 16-bit [q_rows][H*64] token-major
+  int H;
+  int q_rows;          // total query rows (all sequences)
+  int seq_len;         // rows per sequence; query row r attends keys of sequence r / seq_len
+  int q_head_stride;   // rows per head in Q
+  int kv_head_stride;  // rows per head in one K/V chunk
+  int kv_chunks;       // global attention over gathered shards: K/V = kv_chunks x [H][kv_head_stride][64]
+  long long kv_chunk_stride;  // elements between chunks
+  int kv_rows_per_chunk;      // valid rows per head in each chunk (when kv_chunks > 1)
+  int dtype;
+};
+hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ elementwise (elementwise.hip)
+// LayerNorm over the last dim with row remapping: out row (g*out_group + out_off + q) <- in row
+// (g*in_group + in_off + q), q < rows_per_group, g < groups.  Output 16-bit or f32.
+struct WmLnArgs {
+  const float* x; void* y; const float* w; const float* b;
+  int D, ld_in, ld_out; float eps;
+  int groups, rows_per_group, in_group, in_off, out_group, out_off;
+  int out_f32, dtype;
+};
+hipError_t wm_launch_layernorm(const WmLnArgs& a, hipStream_t s);
+
+// qkv f32 [M][3*D] -> Q,K,V 16-bit [H][M][64] with optional per-head LayerNorm(64) and 2-D RoPE
+struct WmQkvArgs {
+  const float* qkv; void* q; void* k; void* v;
+  const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;  // null = no qk-norm
+  const float* rope_cos; const float* rope_sin;                                  // [max_pos][16], null = no rope
+  int M, H, head_stride;   // head_stride = rows per head in the outputs
+  int tokens_per_view, patch_start, grid_w;  // position of token t: special (0,0) or (y+1, x+1)
+  float q_scale; int dtype;
+};
+hipError_t wm_launch_qkv_post(const WmQkvArgs& a, hipStream_t s);
+
+// images f32 [N][C][H][W] -> im2col rows [N*gh*gw][Kpad] 16-bit, (x-mean)/std per channel when norm
+hipError_t wm_launch_im2col(const float* img, void* out, int N, int C, int H, int W, int ps, int Kpad,
+                            int normalize, int dtype, hipStream_t s);
+// DINO tokens: X[n][0]=cls+pos[0]; X[n][1..R]=reg; X[n][1+R+j] = patch[n][j] + pos[1+j]   (f32)
+hipError_t wm_launch_dino_tokens(const float* patch, const float* cls, const float* reg, const float* pos,
+                                 float* X, int N, int hw, int R, int D, hipStream_t s);
+// VGT special tokens: rows [0, psi) of every view: cam, reg x R, (pose, ray)
+hipError_t wm_launch_vgt_special(float* X, const float* cam_tok, const float* reg_tok, const float* pose_tok,
+                                 const float* ray_tok, int N, int P, int R, int D, int cond, int first_view_global,
+                                 hipStream_t s);
+// strided f32 copy (tap halves): dst[r*ld_dst + c] = src[r*ld_src + c]
+hipError_t wm_launch_copy2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, hipStream_t s);
+// NHWC f32 bilinear resize, align_corners=True, optional separable add: c < C/2 ? addx[x][c] : addy[y][c - C/2]
+hipError_t wm_launch_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                              const float* addx, const float* addy, hipStream_t s);
+// out = a + b (f32), n elements
+hipError_t wm_launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s);
+// DPT tail: y32 f32 NHWC [n][H][W][32] (pre-ReLU) -> relu -> 1x1 (32->C) -> activation; writes attr [n][H][W][C-1], conf [n][H][W]
+hipError_t wm_launch_dpt_tail(const float* y32, const float* w, const float* b, float* attr, float* conf,
+                              size_t npix, int C, int act, hipStream_t s);
+enum { WM_ACT_INV_LOG = 0, WM_ACT_EXP = 1, WM_ACT_NORM = 2 };
+
+// ------------------------------------------------------------------ conv (conv.hip)
+struct WmConvArgs {
+  const float* x;      // NHWC f32 [N][Hi][Wi][Cin]
+  const void* w;       // 16-bit [Cout][ky][kx][Cin]
+  const float* bias;   // [Cout] or null
+  const float* resid;  // NHWC f32 [N][Ho][Wo][Cout] or null; added after bias (relu'd first when resid_relu)
+  const float* resid2; // second, plain residual or null
+  float* y;            // NHWC f32 [N][Ho][Wo][Cout]
+  int N, Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad;
+  int relu_in, resid_relu, relu_out, dtype;
+};
+hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ camera head / small fp32 ops (small.hip)
+// Y[M][N] = act(X[M][K]) * W[N][K]^T + b ; all f32.  pre_act: 0 none, 1 SiLU on X.  post: 0 none, 1 SiLU, 2 GELU(erf)
+hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, float* Y, int M, int N, int K,
+                                int ldx, int ldy, int pre_act, int post_act, const float* gamma, int accumulate,
+                                hipStream_t s);
+// f32 attention over S tokens: qkv [S][3*D] -> out [S][D], heads x hd
+hipError_t wm_launch_small_attention(const float* qkv, float* out, int S, int heads, int hd, hipStream_t s);
+// h = gate * (LN_noaffine(tok) * (1 + scale) + shift) + tok ; mod = [S][3*D] (shift, scale, gate)
+hipError_t wm_launch_adaln(const float* tok, const float* mod, float* h, int S, int D, float eps, hipStream_t s);
+// camera activation + accumulate: pred[S][12] (+)= delta[S][12] ; out[S][9] = [t, quat, relu(fov)]
+hipError_t wm_launch_cam_update(float* pred, const float* delta, float* out, int S, int first, hipStream_t s);
+// camera_params [S][9] -> c2w [S][16], K [S][9]  (camera_utils.py:46-75, worldmirror.py:165-175)
+hipError_t wm_launch_cam_matrices(const float* params, float* poses, float* intrs, int S, int H, int W, hipStream_t s);

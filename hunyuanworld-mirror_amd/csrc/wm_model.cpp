@@ -1,0 +1,1179 @@
+// Host orchestrator + C ABI (include/wm_hip.h) of the MI355X-native WorldMirror forward pass.
+//
+// One wm_handle = one process/GPU: owns the repacked weights and a workspace arena, and turns
+// WorldMirror.forward (reference src/models/models/worldmirror.py:120-216) into a fixed sequence of
+// HIP kernel launches on the caller's stream.  No torch, no hidden per-call allocation once the
+// workspace for a shape exists.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <pthread.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/wm_hip.h"
+#include "wm_kernels.h"
+
+namespace {
+
+inline int ru(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------ host 16-bit conversion
+inline uint16_t h_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline uint16_t h_f2h(float f) {
+  _Float16 h = (_Float16)f;
+  uint16_t r;
+  memcpy(&r, &h, 2);
+  return r;
+}
+inline uint16_t h_to16(float f, int dt) { return dt == WM_DT_BF16 ? h_f2bf(f) : h_f2h(f); }
+
+struct Weight {
+  std::vector<int64_t> shape;
+  float* f32 = nullptr;  // device
+  void* w16 = nullptr;   // device 16-bit repack
+  int k16 = 0;           // padded K of the repack
+  std::vector<float> host;  // kept only for the few tensors the host needs (pos_embed, init_token)
+  bool set = false;
+};
+
+struct EvPair { hipEvent_t a, b; };
+
+struct Comm {
+  int kind = 0;  // 0 none, 1 rccl, 2 local
+  int rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  wm_local_group* grp = nullptr;
+};
+
+}  // namespace
+
+struct wm_local_group {
+  int world;
+  pthread_barrier_t bar;
+  std::vector<void*> recv;
+};
+
+struct wm_handle {
+  wm_config cfg;
+  int device = 0;
+  std::string err;
+  std::unordered_map<std::string, Weight> w;
+  std::map<std::string, std::vector<int64_t>> spec;
+  bool finalized = false;
+  Comm comm;
+  // workspace
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int plan_n = -1, plan_nt = -1, plan_H = -1, plan_W = -1;
+  // shape-dependent device tables (allocated inside the arena by plan())
+  std::map<std::string, void*> buf;
+  // profiling
+  bool prof = false;
+  std::vector<EvPair> ev[5];
+  size_t ev_used[5] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+wm_status fail(wm_handle* h, wm_status st, const std::string& msg) {
+  if (h) h->err = msg;
+  return st;
+}
+#define HIPCHK(h, e)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (e);                                                                               \
+    if (_e != hipSuccess)                                                                              \
+      return fail(h, WM_ERR_HIP, std::string(hipGetErrorString(_e)) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+bool starts_with(const std::string& s, const char* p) { return s.compare(0, strlen(p), p) == 0; }
+
+enum WKind { WK_F32, WK_LIN16_BACKBONE, WK_LIN16_HEAD, WK_CONV16_HEAD, WK_CONVT16_HEAD };
+
+WKind classify(const std::string& n, int ndim) {
+  const bool vgt = starts_with(n, "visual_geometry_transformer.");
+  if (vgt && ndim >= 2) {
+    if (ends_with(n, "attn.qkv.weight") || ends_with(n, "attn.proj.weight") || ends_with(n, "mlp.fc1.weight") ||
+        ends_with(n, "mlp.fc2.weight") || ends_with(n, "patch_embed.proj.weight") || ends_with(n, "depth_embed.proj.2.fc1.weight") ||
+        ends_with(n, "depth_embed.proj.2.fc2.weight"))
+      return WK_LIN16_BACKBONE;
+    return WK_F32;
+  }
+  const bool head = starts_with(n, "pts_head.") || starts_with(n, "depth_head.") || starts_with(n, "norm_head.") || starts_with(n, "gs_head.");
+  if (head && ndim == 4 && ends_with(n, ".weight")) {
+    if (ends_with(n, "scratch.output_conv2.2.weight") || n.find("input_merger") != std::string::npos) return WK_F32;
+    if (n.find("resize_layers.0.") != std::string::npos || n.find("resize_layers.1.") != std::string::npos) return WK_CONVT16_HEAD;
+    if (n.find(".projects.") != std::string::npos) return WK_LIN16_HEAD;
+    return WK_CONV16_HEAD;
+  }
+  if (n == "gs_renderer.gs_head.0.weight" || n == "gs_renderer.gs_head.2.weight") return WK_CONV16_HEAD;
+  return WK_F32;
+}
+
+// ------------------------------------------------------------------ parameter list (mirrors config.param_spec)
+void spec_block(std::vector<std::pair<std::string, std::vector<int64_t>>>& s, const std::string& p, int D, int hid, int qk) {
+  auto add = [&](const char* n, std::vector<int64_t> sh) { s.push_back({p + n, sh}); };
+  add("norm1.weight", {D}); add("norm1.bias", {D});
+  add("attn.qkv.weight", {3 * D, D}); add("attn.qkv.bias", {3 * D});
+  if (qk) { add("attn.q_norm.weight", {qk}); add("attn.q_norm.bias", {qk}); add("attn.k_norm.weight", {qk}); add("attn.k_norm.bias", {qk}); }
+  add("attn.proj.weight", {D, D}); add("attn.proj.bias", {D}); add("ls1.gamma", {D});
+  add("norm2.weight", {D}); add("norm2.bias", {D});
+  add("mlp.fc1.weight", {hid, D}); add("mlp.fc1.bias", {hid}); add("mlp.fc2.weight", {D, hid}); add("mlp.fc2.bias", {D});
+  add("ls2.gamma", {D});
+}
+
+std::vector<std::pair<std::string, std::vector<int64_t>>> param_spec(const wm_config& c) {
+  std::vector<std::pair<std::string, std::vector<int64_t>>> s;
+  const int D = c.embed_dim, g = c.img_size / c.patch_size, R = c.num_register_tokens, H4 = c.mlp_ratio * D;
+  const std::string v = "visual_geometry_transformer.", d = v + "patch_embed.";
+  s.push_back({v + "cam_token", {1, 2, 1, D}});
+  s.push_back({v + "reg_token", {1, 2, R, D}});
+  s.push_back({d + "cls_token", {1, 1, D}});
+  s.push_back({d + "pos_embed", {1, 1 + g * g, D}});
+  s.push_back({d + "register_tokens", {1, R, D}});
+  s.push_back({d + "patch_embed.proj.weight", {D, 3, c.patch_size, c.patch_size}});
+  s.push_back({d + "patch_embed.proj.bias", {D}});
+  for (int i = 0; i < c.dino_depth; ++i) spec_block(s, d + "blocks." + std::to_string(i) + ".", D, H4, 0);
+  s.push_back({d + "norm.weight", {D}});
+  s.push_back({d + "norm.bias", {D}});
+  if (c.enable_cond) {
+    s.push_back({v + "pose_embed.0.weight", {D, 7}}); s.push_back({v + "pose_embed.0.bias", {D}});
+    s.push_back({v + "pose_embed.2.weight", {D, D}}); s.push_back({v + "pose_embed.2.bias", {D}});
+    s.push_back({v + "depth_embed.proj.2.fc1.weight", {4 * D, c.patch_size * c.patch_size}});
+    s.push_back({v + "depth_embed.proj.2.fc1.bias", {4 * D}});
+    s.push_back({v + "depth_embed.proj.2.fc2.weight", {D, 4 * D}}); s.push_back({v + "depth_embed.proj.2.fc2.bias", {D}});
+    s.push_back({v + "ray_embed.0.weight", {D, 4}}); s.push_back({v + "ray_embed.0.bias", {D}});
+    s.push_back({v + "ray_embed.2.weight", {D, D}}); s.push_back({v + "ray_embed.2.bias", {D}});
+  }
+  for (int i = 0; i < c.depth; ++i) spec_block(s, v + "frame_blocks." + std::to_string(i) + ".", D, H4, D / c.num_heads);
+  for (int i = 0; i < c.depth; ++i) spec_block(s, v + "global_blocks." + std::to_string(i) + ".", D, H4, D / c.num_heads);
+  const int D2 = 2 * D;
+  if (c.enable_cam) {
+    const std::string ch = "cam_head.";
+    for (int i = 0; i < c.cam_trunk_depth; ++i) spec_block(s, ch + "refine_net." + std::to_string(i) + ".", D2, 4 * D2, 0);
+    s.push_back({ch + "token_norm.weight", {D2}}); s.push_back({ch + "token_norm.bias", {D2}});
+    s.push_back({ch + "out_norm.weight", {D2}}); s.push_back({ch + "out_norm.bias", {D2}});
+    s.push_back({ch + "init_token", {1, 1, 9}});
+    s.push_back({ch + "param_embed.weight", {D2, 9}}); s.push_back({ch + "param_embed.bias", {D2}});
+    s.push_back({ch + "adapt_norm_gen.1.weight", {3 * D2, D2}}); s.push_back({ch + "adapt_norm_gen.1.bias", {3 * D2}});
+    s.push_back({ch + "param_predictor.fc1.weight", {D2 / 2, D2}}); s.push_back({ch + "param_predictor.fc1.bias", {D2 / 2}});
+    s.push_back({ch + "param_predictor.fc2.weight", {9, D2 / 2}}); s.push_back({ch + "param_predictor.fc2.bias", {9}});
+  }
+  auto dpt = [&](const std::string& p, int F, int od, bool gs) {
+    const int32_t* oc = c.dpt_out_channels;
+    s.push_back({p + "norm.weight", {D2}}); s.push_back({p + "norm.bias", {D2}});
+    for (int i = 0; i < 4; ++i) {
+      s.push_back({p + "projects." + std::to_string(i) + ".weight", {oc[i], D2, 1, 1}});
+      s.push_back({p + "projects." + std::to_string(i) + ".bias", {oc[i]}});
+    }
+    s.push_back({p + "resize_layers.0.weight", {oc[0], oc[0], 4, 4}}); s.push_back({p + "resize_layers.0.bias", {oc[0]}});
+    s.push_back({p + "resize_layers.1.weight", {oc[1], oc[1], 2, 2}}); s.push_back({p + "resize_layers.1.bias", {oc[1]}});
+    s.push_back({p + "resize_layers.3.weight", {oc[3], oc[3], 3, 3}}); s.push_back({p + "resize_layers.3.bias", {oc[3]}});
+    for (int i = 0; i < 4; ++i) s.push_back({p + "scratch.layer" + std::to_string(i + 1) + "_rn.weight", {F, oc[i], 3, 3}});
+    for (int r = 1; r <= 4; ++r) {
+      const std::string q = p + "scratch.refinenet" + std::to_string(r) + ".";
+      s.push_back({q + "out_conv.weight", {F, F, 1, 1}}); s.push_back({q + "out_conv.bias", {F}});
+      for (int u = (r == 4 ? 2 : 1); u <= 2; ++u)
+        for (int cv = 1; cv <= 2; ++cv) {
+          const std::string nm = q + "resConfUnit" + std::to_string(u) + ".conv" + std::to_string(cv);
+          s.push_back({nm + ".weight", {F, F, 3, 3}}); s.push_back({nm + ".bias", {F}});
+        }
+    }
+    s.push_back({p + "scratch.output_conv1.weight", {F / 2, F, 3, 3}}); s.push_back({p + "scratch.output_conv1.bias", {F / 2}});
+    s.push_back({p + "scratch.output_conv2.0.weight", {32, F / 2, 3, 3}}); s.push_back({p + "scratch.output_conv2.0.bias", {32}});
+    s.push_back({p + "scratch.output_conv2.2.weight", {od, 32, 1, 1}}); s.push_back({p + "scratch.output_conv2.2.bias", {od}});
+    if (gs) { s.push_back({p + "input_merger.0.weight", {F / 2, 3, 7, 7}}); s.push_back({p + "input_merger.0.bias", {F / 2}}); }
+  };
+  if (c.enable_pts) dpt("pts_head.", c.dpt_features, 4, false);
+  if (c.enable_depth) dpt("depth_head.", c.dpt_features, 2, false);
+  if (c.enable_norm) dpt("norm_head.", c.dpt_features, 4, false);
+  if (c.enable_gs) {
+    dpt("gs_head.", c.gs_dim, 2, true);
+    s.push_back({"gs_renderer.gs_head.0.weight", {c.gs_dim, c.gs_dim / 2, 3, 3}});
+    s.push_back({"gs_renderer.gs_head.2.weight", {12, c.gs_dim, 1, 1}});
+    s.push_back({"gs_renderer.gs_head.2.bias", {12}});
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------ small accessors
+const Weight* W(const wm_handle* h, const std::string& n) {
+  auto it = h->w.find(n);
+  return it == h->w.end() ? nullptr : &it->second;
+}
+const float* F(const wm_handle* h, const std::string& n) {
+  const Weight* w = W(h, n);
+  return w ? w->f32 : nullptr;
+}
+const void* W16(const wm_handle* h, const std::string& n) {
+  const Weight* w = W(h, n);
+  return w ? w->w16 : nullptr;
+}
+
+struct Dims {
+  int n, nt, H, W, gh, gw, hw, Td, P, psi, D, heads, R, Md, Mv, Mx, kpad_patch, kpad_depth, world, chunk;
+  int gh2, gw2;
+};
+
+Dims make_dims(const wm_handle* h, int n, int nt, int H, int W) {
+  const wm_config& c = h->cfg;
+  Dims d;
+  d.n = n; d.nt = nt; d.H = H; d.W = W;
+  d.gh = H / c.patch_size; d.gw = W / c.patch_size; d.hw = d.gh * d.gw;
+  d.R = c.num_register_tokens;
+  d.Td = 1 + d.R + d.hw;
+  d.psi = 1 + d.R + (c.enable_cond ? 2 : 0);
+  d.P = d.psi + d.hw;
+  d.D = c.embed_dim; d.heads = c.num_heads;
+  d.Md = n * d.Td; d.Mv = n * d.P; d.Mx = std::max(d.Md, d.Mv);
+  d.kpad_patch = ru(3 * c.patch_size * c.patch_size, 64);
+  d.kpad_depth = ru(c.patch_size * c.patch_size, 64);
+  d.world = nt / std::max(n, 1);
+  d.chunk = std::min(n, 8);
+  d.gh2 = (d.gh + 2 - 3) / 2 + 1; d.gw2 = (d.gw + 2 - 3) / 2 + 1;
+  return d;
+}
+
+// arena layout: name -> bytes (in a fixed order)
+std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, const Dims& d) {
+  const wm_config& c = h->cfg;
+  std::vector<std::pair<std::string, size_t>> L;
+  auto add = [&](const char* n, size_t b) { L.push_back({n, (b + 255) / 256 * 256}); };
+  const size_t D = d.D, Mx = d.Mx, Mv = d.Mv;
+  add("Xd", (size_t)d.Md * D * 4);
+  add("Xv", Mv * D * 4);
+  add("A16", Mx * std::max<size_t>({D, (size_t)d.kpad_patch, (size_t)d.kpad_depth}) * 2);
+  add("QKV32", Mx * 3 * D * 4);
+  add("QKV16", 3 * Mx * D * 2);
+  add("O16", Mx * D * 2);
+  add("H16", Mx * 4 * D * 2);
+  for (int i = 0; i < 4; ++i) add(("tap" + std::to_string(i)).c_str(), Mv * 2 * D * 4);
+  if (d.world > 1) add("KVG", (size_t)d.world * 2 * Mv * D * 2);
+  add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
+  add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
+  add("dino_pos", (size_t)(1 + d.hw) * D * 4);
+  // priors
+  add("pr_in", (size_t)d.n * 16 * 4);
+  add("pr_h", (size_t)d.n * D * 4);
+  add("pose_tok", (size_t)d.n * D * 4);
+  add("ray_tok", (size_t)d.n * D * 4);
+  // camera head (fp32, all views)
+  const size_t D2 = 2 * D, nt = d.nt;
+  add("cam_tok_local", (size_t)d.n * D2 * 4);
+  add("cam_tok", nt * D2 * 4);
+  add("cam_e", nt * D2 * 4);
+  add("cam_mod", nt * 3 * D2 * 4);
+  add("cam_h", nt * D2 * 4);
+  add("cam_a", nt * D2 * 4);
+  add("cam_qkv", nt * 3 * D2 * 4);
+  add("cam_o", nt * D2 * 4);
+  add("cam_f", nt * 4 * D2 * 4);
+  add("cam_pred", nt * 12 * 4);
+  add("cam_delta", nt * 12 * 4);
+  add("cam_init", nt * 12 * 4);
+  add("cam_params", nt * 9 * 4);
+  // DPT heads
+  const int32_t* oc = c.dpt_out_channels;
+  const size_t ch = d.chunk, hw = d.hw;
+  const int Fm = std::max(c.dpt_features, c.enable_gs ? c.gs_dim : 0);
+  add("dpt_T16", ch * hw * D2 * 2);
+  add("dpt_P16", ch * hw * std::max(oc[0], oc[1]) * 2);
+  add("dpt_f0", ch * 16 * hw * oc[0] * 4);
+  add("dpt_f1", ch * 4 * hw * oc[1] * 4);
+  add("dpt_f2", ch * hw * oc[2] * 4);
+  add("dpt_f3in", ch * hw * oc[3] * 4);
+  add("dpt_f3", ch * (size_t)d.gh2 * d.gw2 * oc[3] * 4);
+  add("dpt_rn1", ch * 16 * hw * Fm * 4);
+  add("dpt_rn2", ch * 4 * hw * Fm * 4);
+  add("dpt_rn3", ch * hw * Fm * 4);
+  add("dpt_rn4", ch * (size_t)d.gh2 * d.gw2 * Fm * 4);
+  const size_t big = ch * std::max<size_t>({64 * hw * (size_t)Fm, (size_t)d.H * d.W * (Fm / 2), (size_t)d.H * d.W * 32}) * 4;
+  for (int i = 0; i < 4; ++i) add(("dpt_s" + std::to_string(i)).c_str(), big);
+  for (int i = 0; i < 4; ++i) add(("dpt_pos" + std::to_string(i)).c_str(), hw * oc[i] * 4);
+  add("dpt_posx", (size_t)d.W * (Fm / 4) * 4 * 2);  // one table per feature width (F/2 channels -> F/4 per axis)
+  add("dpt_posy", (size_t)d.H * (Fm / 4) * 4 * 2);
+  add("gs_posx", (size_t)d.W * (Fm / 4) * 4 * 2);
+  add("gs_posy", (size_t)d.H * (Fm / 4) * 4 * 2);
+  return L;
+}
+
+template <class T> T* B(wm_handle* h, const char* n) { return (T*)h->buf.at(n); }
+
+// torch.linspace(start, end, steps, dtype=float32) (symmetric evaluation, as ATen does)
+void linspace_f32(float start, float end, int steps, std::vector<float>& out) {
+  out.resize(steps);
+  if (steps == 1) { out[0] = start; return; }
+  const float step = (end - start) / (float)(steps - 1);
+  const int half = steps / 2;
+  for (int i = 0; i < steps; ++i) out[i] = i < half ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+// src/models/utils/grid.py:4-90 — separable halves of 0.1 * position_grid_to_embed(create_uv_grid(w,h,aspect), C)
+void uv_tables(int w, int hgt, int C, double aspect, std::vector<float>& tx, std::vector<float>& ty) {
+  const double diag = std::sqrt(aspect * aspect + 1.0), sx = aspect / diag, sy = 1.0 / diag;
+  std::vector<float> u, v;
+  linspace_f32((float)(-sx * (w - 1) / w), (float)(sx * (w - 1) / w), w, u);
+  linspace_f32((float)(-sy * (hgt - 1) / hgt), (float)(sy * (hgt - 1) / hgt), hgt, v);
+  const int q = C / 4;
+  std::vector<double> om(q);
+  for (int k = 0; k < q; ++k) om[k] = 1.0 / std::pow(100.0, (double)k / (C / 4.0));
+  tx.assign((size_t)w * 2 * q, 0.f);
+  ty.assign((size_t)hgt * 2 * q, 0.f);
+  for (int x = 0; x < w; ++x)
+    for (int k = 0; k < q; ++k) {
+      tx[(size_t)x * 2 * q + k] = (float)std::sin((double)u[x] * om[k]) * 0.1f;
+      tx[(size_t)x * 2 * q + q + k] = (float)std::cos((double)u[x] * om[k]) * 0.1f;
+    }
+  for (int y = 0; y < hgt; ++y)
+    for (int k = 0; k < q; ++k) {
+      ty[(size_t)y * 2 * q + k] = (float)std::sin((double)v[y] * om[k]) * 0.1f;
+      ty[(size_t)y * 2 * q + q + k] = (float)std::cos((double)v[y] * om[k]) * 0.1f;
+    }
+}
+
+// ATen's separable anti-aliased bicubic (a = -0.5), align_corners=False — vision_transformer.py:196-201
+inline double cubic_aa(double x) {
+  const double a = -0.5;
+  x = std::fabs(x);
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0;
+  if (x < 2.0) return (((x - 5.0) * x + 8.0) * x - 4.0) * a;
+  return 0.0;
+}
+void aa_weights(int in, int out, std::vector<int>& xmin, std::vector<int>& xsize, std::vector<float>& wts, int& maxk) {
+  const double scale = (double)in / out;
+  const double support = scale >= 1.0 ? 2.0 * scale : 2.0;
+  const double invscale = scale >= 1.0 ? 1.0 / scale : 1.0;
+  maxk = (int)std::ceil(support) * 2 + 1;
+  xmin.resize(out); xsize.resize(out); wts.assign((size_t)out * maxk, 0.f);
+  for (int i = 0; i < out; ++i) {
+    const double center = scale * (i + 0.5);
+    const int lo = std::max(0, (int)(center - support + 0.5));
+    const int hi = std::min(in, (int)(center + support + 0.5));
+    xmin[i] = lo; xsize[i] = hi - lo;
+    double tot = 0;
+    std::vector<double> w(hi - lo);
+    for (int j = 0; j < hi - lo; ++j) { w[j] = cubic_aa((j + lo - center + 0.5) * invscale); tot += w[j]; }
+    for (int j = 0; j < hi - lo; ++j) wts[(size_t)i * maxk + j] = (float)(w[j] / tot);
+  }
+}
+
+}  // namespace
+
+extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int gw, float* out) {
+  // in [gs][gs][D] -> out [gh][gw][D]; horizontal pass then vertical pass (ATen order)
+  std::vector<int> xm, xs, ym, ys;
+  std::vector<float> xw, yw;
+  int kx, ky;
+  aa_weights(gs, gw, xm, xs, xw, kx);
+  aa_weights(gs, gh, ym, ys, yw, ky);
+  std::vector<float> tmp((size_t)gs * gw * D);
+  for (int y = 0; y < gs; ++y)
+    for (int x = 0; x < gw; ++x) {
+      float* o = &tmp[((size_t)y * gw + x) * D];
+      for (int c = 0; c < D; ++c) o[c] = 0.f;
+      for (int j = 0; j < xs[x]; ++j) {
+        const float w = xw[(size_t)x * kx + j];
+        const float* s = in + ((size_t)y * gs + xm[x] + j) * D;
+        for (int c = 0; c < D; ++c) o[c] += w * s[c];
+      }
+    }
+  for (int y = 0; y < gh; ++y)
+    for (int x = 0; x < gw; ++x) {
+      float* o = out + ((size_t)y * gw + x) * D;
+      for (int c = 0; c < D; ++c) o[c] = 0.f;
+      for (int j = 0; j < ys[y]; ++j) {
+        const float w = yw[(size_t)y * ky + j];
+        const float* s = &tmp[((size_t)(ym[y] + j) * gw + x) * D];
+        for (int c = 0; c < D; ++c) o[c] += w * s[c];
+      }
+    }
+}
+
+extern "C" void wm_host_to_16(const float* in, uint16_t* out, size_t n, int dtype) {
+  for (size_t i = 0; i < n; ++i) out[i] = h_to16(in[i], dtype);
+}
+
+// ====================================================================================== lifecycle
+extern "C" wm_status wm_create(const wm_config* cfg, int device, wm_handle** out) {
+  if (!cfg || !out) return WM_ERR_INVALID;
+  wm_handle* h = new wm_handle();
+  h->cfg = *cfg;
+  h->device = device;
+  *out = h;
+  if (cfg->embed_dim / cfg->num_heads != 64 || cfg->embed_dim / cfg->dino_heads != 64)
+    return fail(h, WM_ERR_INVALID, "backbone head_dim must be 64 (reference: 1024/16)");
+  if (cfg->num_heads % 4 && cfg->num_heads != 2) return fail(h, WM_ERR_INVALID, "num_heads must be 2 or a multiple of 4");
+  if (cfg->embed_dim % 64) return fail(h, WM_ERR_INVALID, "embed_dim must be a multiple of 64");
+  if (hipSetDevice(device) != hipSuccess) return fail(h, WM_ERR_HIP, "hipSetDevice failed");
+  return WM_OK;
+}
+
+extern "C" void wm_destroy(wm_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (auto& kv : h->w) {
+    if (kv.second.f32) (void)hipFree(kv.second.f32);
+    if (kv.second.w16) (void)hipFree(kv.second.w16);
+  }
+  if (h->arena) (void)hipFree(h->arena);
+  for (int k = 0; k < 5; ++k)
+    for (auto& e : h->ev[k]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (h->comm.kind == 1 && h->comm.nccl) ncclCommDestroy(h->comm.nccl);
+  delete h;
+}
+
+extern "C" const char* wm_last_error(const wm_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* host, const int64_t* shape, int ndim) {
+  if (!h || !name || !host || !shape) return WM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const std::string n(name);
+  // strict=False: names outside the spec are ignored
+  auto& spec = h->spec;
+  if (spec.empty())
+    for (auto& kv : param_spec(h->cfg)) spec[kv.first] = kv.second;
+  auto it = spec.find(n);
+  if (it == spec.end()) return WM_OK;
+  std::vector<int64_t> sh(shape, shape + ndim);
+  if (sh != it->second) return fail(h, WM_ERR_INVALID, "shape mismatch for " + n);
+  size_t numel = 1;
+  for (auto s : sh) numel *= (size_t)s;
+  Weight& w = h->w[n];
+  if (w.f32) { (void)hipFree(w.f32); w.f32 = nullptr; }
+  if (w.w16) { (void)hipFree(w.w16); w.w16 = nullptr; }
+  w.shape = sh;
+  w.set = true;
+  const WKind k = classify(n, ndim);
+  if (k == WK_F32) {
+    HIPCHK(h, hipMalloc((void**)&w.f32, std::max<size_t>(numel, 4) * 4));
+    HIPCHK(h, hipMemcpy(w.f32, host, numel * 4, hipMemcpyHostToDevice));
+    if (ends_with(n, "pos_embed") || ends_with(n, "init_token")) w.host.assign(host, host + numel);
+    return WM_OK;
+  }
+  const int dt = k == WK_LIN16_BACKBONE ? h->cfg.backbone_dtype : h->cfg.head_dtype;
+  std::vector<uint16_t> r;
+  if (k == WK_LIN16_BACKBONE || k == WK_LIN16_HEAD) {
+    const int N = (int)sh[0];
+    const int K = (int)(numel / N);
+    const int Kp = ru(K, 64);
+    r.assign((size_t)N * Kp, 0);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < K; ++j) r[(size_t)i * Kp + j] = h_to16(host[(size_t)i * K + j], dt);
+    w.k16 = Kp;
+  } else if (k == WK_CONV16_HEAD) {  // [Cout][Cin][kh][kw] -> [Cout][kh][kw][Cin]
+    const int Co = (int)sh[0], Ci = (int)sh[1], kh = (int)sh[2], kw = (int)sh[3];
+    r.resize(numel);
+    for (int o = 0; o < Co; ++o)
+      for (int c = 0; c < Ci; ++c)
+        for (int y = 0; y < kh; ++y)
+          for (int x = 0; x < kw; ++x)
+            r[(((size_t)o * kh + y) * kw + x) * Ci + c] = h_to16(host[(((size_t)o * Ci + c) * kh + y) * kw + x], dt);
+    w.k16 = kh * kw * Ci;
+  } else {  // ConvTranspose2d [Cin][Cout][k][k] -> rows (i*k + j)*Cout + co, K = Cin
+    const int Ci = (int)sh[0], Co = (int)sh[1], kk = (int)sh[2];
+    r.resize(numel);
+    for (int c = 0; c < Ci; ++c)
+      for (int o = 0; o < Co; ++o)
+        for (int i = 0; i < kk; ++i)
+          for (int j = 0; j < kk; ++j)
+            r[((size_t)(i * kk + j) * Co + o) * Ci + c] = h_to16(host[(((size_t)c * Co + o) * kk + i) * kk + j], dt);
+    w.k16 = Ci;
+  }
+  HIPCHK(h, hipMalloc(&w.w16, r.size() * 2));
+  HIPCHK(h, hipMemcpy(w.w16, r.data(), r.size() * 2, hipMemcpyHostToDevice));
+  return WM_OK;
+}
+
+extern "C" wm_status wm_finalize_weights(wm_handle* h, int* missing) {
+  if (!h) return WM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  int miss = 0;
+  for (auto& kv : param_spec(h->cfg)) {
+    auto it = h->w.find(kv.first);
+    if (it != h->w.end() && it->second.set) continue;
+    ++miss;  // strict=False: a missing tensor stays zero
+    size_t numel = 1;
+    for (auto s : kv.second) numel *= (size_t)s;
+    std::vector<float> z(numel, 0.f);
+    wm_status st = wm_set_weight(h, kv.first.c_str(), z.data(), kv.second.data(), (int)kv.second.size());
+    if (st != WM_OK) return st;
+    h->w[kv.first].set = false;
+  }
+  if (missing) *missing = miss;
+  h->finalized = true;
+  return WM_OK;
+}
+
+// ====================================================================================== workspace
+extern "C" size_t wm_workspace_bytes(const wm_handle* h, int n_local, int n_total, int H, int W) {
+  if (!h) return 0;
+  const Dims d = make_dims(h, n_local, n_total, H, W);
+  size_t tot = 0;
+  for (auto& kv : arena_layout(h, d)) tot += kv.second;
+  return tot;
+}
+
+namespace {
+
+wm_status plan(wm_handle* h, const Dims& d, hipStream_t s) {
+  if (h->plan_n == d.n && h->plan_nt == d.nt && h->plan_H == d.H && h->plan_W == d.W) return WM_OK;
+  const wm_config& c = h->cfg;
+  auto L = arena_layout(h, d);
+  size_t tot = 0;
+  for (auto& kv : L) tot += kv.second;
+  HIPCHK(h, hipStreamSynchronize(s));
+  if (tot > h->arena_bytes) {
+    if (h->arena) HIPCHK(h, hipFree(h->arena));
+    h->arena = nullptr;
+    HIPCHK(h, hipMalloc((void**)&h->arena, tot));
+    h->arena_bytes = tot;
+  }
+  h->buf.clear();
+  size_t off = 0;
+  for (auto& kv : L) { h->buf[kv.first] = h->arena + off; off += kv.second; }
+
+  // RoPE tables (rope.py:80-111): angle = pos * 100^(-i/16), i < 16 (table is cat(ang, ang): index e % 16)
+  {
+    const int np = std::max(d.gh, d.gw) + 1;
+    std::vector<float> cs((size_t)np * 16), sn((size_t)np * 16);
+    for (int p = 0; p < np; ++p)
+      for (int i = 0; i < 16; ++i) {
+        const float expo = (float)(2 * i) / 32.0f;
+        const float inv = 1.0f / std::pow(c.rope_freq, expo);
+        const float ang = (float)p * inv;
+        cs[(size_t)p * 16 + i] = std::cos(ang);
+        sn[(size_t)p * 16 + i] = std::sin(ang);
+      }
+    HIPCHK(h, hipMemcpy(h->buf["rope_cos"], cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->buf["rope_sin"], sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+  }
+  // DINO pos-embed for this grid (vision_transformer.py:175-207)
+  {
+    const Weight* pe = W(h, "visual_geometry_transformer.patch_embed.pos_embed");
+    if (!pe || pe->host.empty()) return fail(h, WM_ERR_STATE, "pos_embed not set");
+    const int g = c.img_size / c.patch_size, D = d.D;
+    if (d.gh == g && d.gw == g) {
+      HIPCHK(h, hipMemcpy(h->buf["dino_pos"], pe->host.data(), (size_t)(1 + d.hw) * D * 4, hipMemcpyHostToDevice));
+    } else {
+      std::vector<float> r((size_t)(1 + d.hw) * D);
+      memcpy(r.data(), pe->host.data(), (size_t)D * 4);
+      wm_host_resample_pos(pe->host.data() + D, g, D, d.gh, d.gw, r.data() + D);
+      HIPCHK(h, hipMemcpy(h->buf["dino_pos"], r.data(), r.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  // DPT UV position tables (dense_head.py:253-263)
+  {
+    const double aspect = (double)d.W / (double)d.H;
+    std::vector<float> tx, ty;
+    for (int i = 0; i < 4; ++i) {
+      const int C = c.dpt_out_channels[i];
+      uv_tables(d.gw, d.gh, C, aspect, tx, ty);
+      std::vector<float> full((size_t)d.hw * C);
+      for (int y = 0; y < d.gh; ++y)
+        for (int x = 0; x < d.gw; ++x)
+          for (int k = 0; k < C; ++k)
+            full[((size_t)y * d.gw + x) * C + k] = k < C / 2 ? tx[(size_t)x * (C / 2) + k] : ty[(size_t)y * (C / 2) + k - C / 2];
+      HIPCHK(h, hipMemcpy(h->buf["dpt_pos" + std::to_string(i)], full.data(), full.size() * 4, hipMemcpyHostToDevice));
+    }
+    uv_tables(d.W, d.H, c.dpt_features / 2, aspect, tx, ty);
+    HIPCHK(h, hipMemcpy(h->buf["dpt_posx"], tx.data(), tx.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->buf["dpt_posy"], ty.data(), ty.size() * 4, hipMemcpyHostToDevice));
+    if (c.enable_gs) {
+      uv_tables(d.W, d.H, c.gs_dim / 2, aspect, tx, ty);
+      HIPCHK(h, hipMemcpy(h->buf["gs_posx"], tx.data(), tx.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(h, hipMemcpy(h->buf["gs_posy"], ty.data(), ty.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  // camera init token broadcast [nt][12]
+  if (c.enable_cam) {
+    const Weight* it = W(h, "cam_head.init_token");
+    std::vector<float> v((size_t)d.nt * 12, 0.f);
+    if (it && !it->host.empty())
+      for (int i = 0; i < d.nt; ++i)
+        for (int k = 0; k < 9; ++k) v[(size_t)i * 12 + k] = it->host[k];
+    HIPCHK(h, hipMemcpy(h->buf["cam_init"], v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  }
+  h->plan_n = d.n; h->plan_nt = d.nt; h->plan_H = d.H; h->plan_W = d.W;
+  return WM_OK;
+}
+
+// ---------------------------------------------------------------- profiling helpers
+struct ProfScope {
+  wm_handle* h; int kind; hipStream_t s; EvPair* e = nullptr;
+  ProfScope(wm_handle* h_, int k, hipStream_t s_) : h(h_), kind(k), s(s_) {
+    if (!h->prof) return;
+    auto& v = h->ev[kind];
+    if (h->ev_used[kind] == v.size()) {
+      EvPair p;
+      (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b);
+      v.push_back(p);
+    }
+    e = &v[h->ev_used[kind]++];
+    (void)hipEventRecord(e->a, s);
+  }
+  ~ProfScope() { if (e) (void)hipEventRecord(e->b, s); }
+};
+
+// ---------------------------------------------------------------- collective
+wm_status comm_allgather(wm_handle* h, const void* send, void* recv, size_t bytes, hipStream_t s) {
+  Comm& cm = h->comm;
+  if (cm.kind == 1) {
+    if (ncclAllGather(send, recv, bytes, ncclInt8, cm.nccl, s) != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclAllGather failed");
+    return WM_OK;
+  }
+  if (cm.kind == 2) {
+    wm_local_group* g = cm.grp;
+    g->recv[cm.rank] = recv;
+    HIPCHK(h, hipStreamSynchronize(s));
+    pthread_barrier_wait(&g->bar);
+    for (int r = 0; r < g->world; ++r)
+      HIPCHK(h, hipMemcpyAsync((char*)g->recv[r] + (size_t)cm.rank * bytes, send, bytes, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    pthread_barrier_wait(&g->bar);
+    return WM_OK;
+  }
+  return fail(h, WM_ERR_COMM, "sharded forward without a communicator");
+}
+
+// ---------------------------------------------------------------- building blocks
+struct Ctx {
+  wm_handle* h; Dims d; hipStream_t s; int bdt, hdt;
+};
+
+#define LCHK(c, e)                                                                                            \
+  do {                                                                                                        \
+    hipError_t _e = (e);                                                                                      \
+    if (_e != hipSuccess)                                                                                     \
+      return fail((c).h, WM_ERR_HIP, std::string(hipGetErrorString(_e)) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+wm_status gemm(Ctx& c, int dt, int epi, const void* A, int lda, const void* Wp, int ldw, void* C, int ldc, const float* bias,
+               const float* gamma, int M, int N, int K, WmGemmArgs* extra = nullptr) {
+  WmGemmArgs a;
+  if (extra) a = *extra; else memset(&a, 0, sizeof(a));
+  a.A = A; a.W = Wp; a.C = C; a.bias = bias; a.gamma = gamma;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.dtype = dt; a.epi = epi;
+  ProfScope ps(c.h, 2, c.s);
+  LCHK(c, wm_launch_gemm(a, c.s));
+  return WM_OK;
+}
+
+wm_status layernorm(Ctx& c, const float* x, int ld_in, void* y, int ld_out, const float* w, const float* b, int D, float eps,
+                    int groups, int rpg, int in_group, int in_off, int out_group, int out_off, int out_f32, int dt) {
+  WmLnArgs a;
+  a.x = x; a.y = y; a.w = w; a.b = b; a.D = D; a.ld_in = ld_in; a.ld_out = ld_out; a.eps = eps;
+  a.groups = groups; a.rows_per_group = rpg; a.in_group = in_group; a.in_off = in_off; a.out_group = out_group; a.out_off = out_off;
+  a.out_f32 = out_f32; a.dtype = dt;
+  LCHK(c, wm_launch_layernorm(a, c.s));
+  return WM_OK;
+}
+
+// Block.forward (block.py:72-93) on the fp32 residual stream X [M][D]; seq_len = attention span.
+wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_len, int heads, float eps, bool qk_norm,
+                         bool rope, int tokens_per_view, int patch_start, bool is_global) {
+  wm_handle* h = c.h;
+  const Dims& d = c.d;
+  const int D = d.D, dt = c.bdt;
+  uint16_t* A16 = B<uint16_t>(h, "A16");
+  float* QKV32 = B<float>(h, "QKV32");
+  char* QKV16 = B<char>(h, "QKV16");
+  const size_t hsz = (size_t)M * D * 2;  // bytes of one of Q/K/V
+  void* Q16 = QKV16; void* K16 = QKV16 + hsz; void* V16 = QKV16 + 2 * hsz;
+  void* O16 = B<void>(h, "O16");
+  void* H16 = B<void>(h, "H16");
+  wm_status st;
+  st = layernorm(c, X, D, A16, D, F(h, p + "norm1.weight"), F(h, p + "norm1.bias"), D, eps, 1, M, 0, 0, 0, 0, 0, dt);
+  if (st) return st;
+  st = gemm(c, dt, WM_EPI_F32, A16, D, W16(h, p + "attn.qkv.weight"), D, QKV32, 3 * D, F(h, p + "attn.qkv.bias"), nullptr, M, 3 * D, D);
+  if (st) return st;
+  {
+    WmQkvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = QKV32; a.q = Q16; a.k = K16; a.v = V16;
+    if (qk_norm) {
+      a.qn_w = F(h, p + "attn.q_norm.weight"); a.qn_b = F(h, p + "attn.q_norm.bias");
+      a.kn_w = F(h, p + "attn.k_norm.weight"); a.kn_b = F(h, p + "attn.k_norm.bias");
+    }
+    if (rope) { a.rope_cos = B<float>(h, "rope_cos"); a.rope_sin = B<float>(h, "rope_sin"); }
+    a.M = M; a.H = heads; a.head_stride = M; a.tokens_per_view = tokens_per_view; a.patch_start = patch_start; a.grid_w = d.gw;
+    a.q_scale = 0.125f; a.dtype = dt;
+    LCHK(c, wm_launch_qkv_post(a, c.s));
+  }
+  {
+    WmAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = Q16; a.O = O16; a.H = heads; a.q_rows = M; a.q_head_stride = M; a.dtype = dt;
+    if (is_global && d.world > 1) {
+      // K and V are adjacent: one all-gather of [K|V] per layer -> [world][2][H][M][64]
+      char* KVG = B<char>(h, "KVG");
+      st = comm_allgather(h, K16, KVG, 2 * hsz, c.s);
+      if (st) return st;
+      a.K = KVG; a.V = KVG + hsz; a.seq_len = M; a.kv_head_stride = M; a.kv_chunks = d.world;
+      a.kv_chunk_stride = (long long)(2 * hsz / 2); a.kv_rows_per_chunk = M;
+    } else {
+      a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
+    }
+    ProfScope ps(h, is_global ? 0 : 1, c.s);
+    LCHK(c, wm_launch_attention(a, c.s));
+  }
+  st = gemm(c, dt, WM_EPI_RESID, O16, D, W16(h, p + "attn.proj.weight"), D, X, D, F(h, p + "attn.proj.bias"), F(h, p + "ls1.gamma"), M, D, D);
+  if (st) return st;
+  st = layernorm(c, X, D, A16, D, F(h, p + "norm2.weight"), F(h, p + "norm2.bias"), D, eps, 1, M, 0, 0, 0, 0, 0, dt);
+  if (st) return st;
+  const int Hd = c.h->cfg.mlp_ratio * D;
+  st = gemm(c, dt, WM_EPI_GELU_T16, A16, D, W16(h, p + "mlp.fc1.weight"), D, H16, Hd, F(h, p + "mlp.fc1.bias"), nullptr, M, Hd, D);
+  if (st) return st;
+  st = gemm(c, dt, WM_EPI_RESID, H16, Hd, W16(h, p + "mlp.fc2.weight"), Hd, X, D, F(h, p + "mlp.fc2.bias"), F(h, p + "ls2.gamma"), M, D, Hd);
+  return st;
+}
+
+wm_status linear32(Ctx& c, const float* X, int ldx, const std::string& name, float* Y, int ldy, int M, int pre, int post,
+                   const float* gamma = nullptr, int accumulate = 0) {
+  const Weight* w = W(c.h, name + ".weight");
+  if (!w || !w->f32) return fail(c.h, WM_ERR_STATE, "missing fp32 weight " + name);
+  const int N = (int)w->shape[0];
+  int K = 1;
+  for (size_t i = 1; i < w->shape.size(); ++i) K *= (int)w->shape[i];
+  LCHK(c, wm_launch_linear_f32(X, w->f32, F(c.h, name + ".bias"), Y, M, N, K, ldx, ldy, pre, post, gamma, accumulate, c.s));
+  return WM_OK;
+}
+
+// CameraHead.forward (camera_head.py:58-104) on all nt views, fp32
+wm_status camera_head(Ctx& c, float* out_params) {
+  wm_handle* h = c.h;
+  const Dims& d = c.d;
+  const wm_config& cf = h->cfg;
+  const int D2 = 2 * d.D, S = d.nt;
+  const std::string ch = "cam_head.";
+  float* tok = B<float>(h, "cam_tok");
+  wm_status st;
+  // token_norm on tap3[:, :, 0]
+  float* tok_local = d.world > 1 ? B<float>(h, "cam_tok_local") : tok;
+  st = layernorm(c, B<float>(h, "tap3"), D2, tok_local, D2, F(h, ch + "token_norm.weight"), F(h, ch + "token_norm.bias"), D2, 1e-5f,
+                 d.n, 1, d.P, 0, 1, 0, 1, 0);
+  if (st) return st;
+  if (d.world > 1) {
+    st = comm_allgather(h, tok_local, tok, (size_t)d.n * D2 * 4, c.s);
+    if (st) return st;
+  }
+  float *e = B<float>(h, "cam_e"), *mod = B<float>(h, "cam_mod"), *hh = B<float>(h, "cam_h"), *a = B<float>(h, "cam_a");
+  float *qkv = B<float>(h, "cam_qkv"), *o = B<float>(h, "cam_o"), *f = B<float>(h, "cam_f");
+  float *pred = B<float>(h, "cam_pred"), *delta = B<float>(h, "cam_delta"), *init = B<float>(h, "cam_init");
+  LCHK(c, hipMemsetAsync(pred, 0, (size_t)S * 12 * 4, c.s));
+  LCHK(c, hipMemsetAsync(delta, 0, (size_t)S * 12 * 4, c.s));
+  for (int step = 0; step < cf.cam_steps; ++step) {
+    st = linear32(c, step == 0 ? init : pred, 12, ch + "param_embed", e, D2, S, 0, 0);
+    if (st) return st;
+    st = linear32(c, e, D2, ch + "adapt_norm_gen.1", mod, 3 * D2, S, 1, 0);
+    if (st) return st;
+    LCHK(c, wm_launch_adaln(tok, mod, hh, S, D2, 1e-6f, c.s));
+    for (int b = 0; b < cf.cam_trunk_depth; ++b) {
+      const std::string p = ch + "refine_net." + std::to_string(b) + ".";
+      st = layernorm(c, hh, D2, a, D2, F(h, p + "norm1.weight"), F(h, p + "norm1.bias"), D2, 1e-5f, 1, S, 0, 0, 0, 0, 1, 0);
+      if (st) return st;
+      st = linear32(c, a, D2, p + "attn.qkv", qkv, 3 * D2, S, 0, 0);
+      if (st) return st;
+      LCHK(c, wm_launch_small_attention(qkv, o, S, cf.cam_heads, D2 / cf.cam_heads, c.s));
+      st = linear32(c, o, D2, p + "attn.proj", hh, D2, S, 0, 0, F(h, p + "ls1.gamma"), 1);
+      if (st) return st;
+      st = layernorm(c, hh, D2, a, D2, F(h, p + "norm2.weight"), F(h, p + "norm2.bias"), D2, 1e-5f, 1, S, 0, 0, 0, 0, 1, 0);
+      if (st) return st;
+      st = linear32(c, a, D2, p + "mlp.fc1", f, 4 * D2, S, 0, 2);
+      if (st) return st;
+      st = linear32(c, f, 4 * D2, p + "mlp.fc2", hh, D2, S, 0, 0, F(h, p + "ls2.gamma"), 1);
+      if (st) return st;
+    }
+    st = layernorm(c, hh, D2, a, D2, F(h, ch + "out_norm.weight"), F(h, ch + "out_norm.bias"), D2, 1e-5f, 1, S, 0, 0, 0, 0, 1, 0);
+    if (st) return st;
+    st = linear32(c, a, D2, ch + "param_predictor.fc1", f, D2 / 2, S, 0, 2);
+    if (st) return st;
+    st = linear32(c, f, D2 / 2, ch + "param_predictor.fc2", delta, 12, S, 0, 0);
+    if (st) return st;
+    LCHK(c, wm_launch_cam_update(pred, delta, out_params, S, step == 0, c.s));
+  }
+  return WM_OK;
+}
+
+wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, const float* resid, bool resid_relu, const float* resid2,
+               float* y, int N, int Hi, int Wi, int ks, int stride, int pad, bool relu_in) {
+  const Weight* w = W(c.h, wname + ".weight");
+  if (!w || !w->w16) return fail(c.h, WM_ERR_STATE, "missing conv weight " + wname);
+  WmConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w->w16; a.bias = bias ? F(c.h, wname + ".bias") : nullptr; a.resid = resid; a.resid2 = resid2; a.y = y;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = (int)w->shape[1]; a.Cout = (int)w->shape[0]; a.ksize = ks; a.stride = stride; a.pad = pad;
+  a.Ho = (Hi + 2 * pad - ks) / stride + 1; a.Wo = (Wi + 2 * pad - ks) / stride + 1;
+  a.relu_in = relu_in; a.resid_relu = resid_relu; a.relu_out = 0; a.dtype = c.hdt;
+  ProfScope ps(c.h, 3, c.s);
+  LCHK(c, wm_launch_conv(a, c.s));
+  return WM_OK;
+}
+
+// ResidualConvUnit (dense_head.py:435-455): y = conv2(relu(conv1(relu x))) + relu(x) (+ extra)
+wm_status rcu(Ctx& c, const std::string& p, const float* x, const float* extra, float* tmp, float* y, int N, int Hh, int Ww) {
+  wm_status st = conv(c, x, p + "conv1", true, nullptr, false, nullptr, tmp, N, Hh, Ww, 3, 1, 1, true);
+  if (st) return st;
+  return conv(c, tmp, p + "conv2", true, x, true, extra, y, N, Hh, Ww, 3, 1, 1, true);
+}
+
+// DPTHead (dense_head.py:107-295) for views [v0, v0+n) of this rank
+wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, bool is_gs, float* out_attr, float* out_conf,
+                   const float* img, float* gs_feat, float* gs_params) {
+  wm_handle* h = c.h;
+  const Dims& d = c.d;
+  const wm_config& cf = h->cfg;
+  const int D2 = 2 * d.D, hw = d.hw, gh = d.gh, gw = d.gw;
+  const int32_t* oc = cf.dpt_out_channels;
+  const std::string sc = p + "scratch.";
+  float* S0 = B<float>(h, "dpt_s0"); float* S1 = B<float>(h, "dpt_s1"); float* S2 = B<float>(h, "dpt_s2"); float* S3 = B<float>(h, "dpt_s3");
+  wm_status st;
+  for (int v0 = 0; v0 < d.n; v0 += d.chunk) {
+    const int n = std::min(d.chunk, d.n - v0);
+    float* feats[4] = {B<float>(h, "dpt_f0"), B<float>(h, "dpt_f1"), B<float>(h, "dpt_f2"), B<float>(h, "dpt_f3")};
+    for (int i = 0; i < 4; ++i) {
+      const float* tap = B<float>(h, ("tap" + std::to_string(i)).c_str()) + (size_t)v0 * d.P * D2;
+      void* T16 = B<void>(h, "dpt_T16");
+      st = layernorm(c, tap, D2, T16, D2, F(h, p + "norm.weight"), F(h, p + "norm.bias"), D2, 1e-5f, n, hw, d.P, d.psi, hw, 0, 0, c.hdt);
+      if (st) return st;
+      const std::string pj = p + "projects." + std::to_string(i);
+      WmGemmArgs ex;
+      memset(&ex, 0, sizeof(ex));
+      ex.rows_per_group = hw; ex.out_group = hw; ex.out_off = 0; ex.add = B<float>(h, ("dpt_pos" + std::to_string(i)).c_str());
+      if (i < 2) {  // feeds a k==stride ConvTranspose (GEMM): 16-bit output
+        ex.out16 = 1;
+        void* P16 = B<void>(h, "dpt_P16");
+        st = gemm(c, c.hdt, WM_EPI_ROWMAP_ADD, T16, D2, W16(h, pj + ".weight"), D2, P16, oc[i], F(h, pj + ".bias"), nullptr, n * hw, oc[i], D2, &ex);
+        if (st) return st;
+        const int k = i == 0 ? 4 : 2;
+        const std::string rs = p + "resize_layers." + std::to_string(i);
+        WmGemmArgs ct;
+        memset(&ct, 0, sizeof(ct));
+        ct.ct_k = k; ct.ct_cout = oc[i]; ct.ct_gh = gh; ct.ct_gw = gw;
+        st = gemm(c, c.hdt, WM_EPI_CONVT, P16, oc[i], W16(h, rs + ".weight"), oc[i], feats[i], 0, F(h, rs + ".bias"), nullptr, n * hw, k * k * oc[i], oc[i], &ct);
+        if (st) return st;
+      } else {
+        float* dst = i == 2 ? feats[2] : B<float>(h, "dpt_f3in");
+        st = gemm(c, c.hdt, WM_EPI_ROWMAP_ADD, T16, D2, W16(h, pj + ".weight"), D2, dst, oc[i], F(h, pj + ".bias"), nullptr, n * hw, oc[i], D2, &ex);
+        if (st) return st;
+        if (i == 3) {
+          st = conv(c, dst, p + "resize_layers.3", true, nullptr, false, nullptr, feats[3], n, gh, gw, 3, 2, 1, false);
+          if (st) return st;
+        }
+      }
+    }
+    const int Hs[4] = {4 * gh, 2 * gh, gh, d.gh2}, Ws[4] = {4 * gw, 2 * gw, gw, d.gw2};
+    float* rn[4] = {B<float>(h, "dpt_rn1"), B<float>(h, "dpt_rn2"), B<float>(h, "dpt_rn3"), B<float>(h, "dpt_rn4")};
+    for (int i = 0; i < 4; ++i) {
+      st = conv(c, feats[i], sc + "layer" + std::to_string(i + 1) + "_rn", false, nullptr, false, nullptr, rn[i], n, Hs[i], Ws[i], 3, 1, 1, false);
+      if (st) return st;
+    }
+    // refinenet4: RCU2(rn4) -> resize to level 3 -> out_conv
+    st = rcu(c, sc + "refinenet4.resConfUnit2.", rn[3], nullptr, S0, S1, n, Hs[3], Ws[3]);
+    if (st) return st;
+    LCHK(c, wm_launch_bilinear(S1, S0, n, Hs[3], Ws[3], Hs[2], Ws[2], F_, nullptr, nullptr, c.s));
+    st = conv(c, S0, sc + "refinenet4.out_conv", true, nullptr, false, nullptr, S2, n, Hs[2], Ws[2], 1, 1, 0, false);
+    if (st) return st;
+    float* cur = S2;  // output of the previous fusion block at level L
+    for (int L = 2; L >= 0; --L) {  // refinenet3 (level 2), refinenet2 (level 1), refinenet1 (level 0)
+      const std::string rp = sc + "refinenet" + std::to_string(L + 1) + ".";
+      float* others[3];
+      int k = 0;
+      for (float* b : {S0, S1, S2, S3}) if (b != cur) others[k++] = b;
+      // x = cur + RCU1(rn[L])
+      st = rcu(c, rp + "resConfUnit1.", rn[L], cur, others[0], others[1], n, Hs[L], Ws[L]);
+      if (st) return st;
+      // x = RCU2(x)
+      st = rcu(c, rp + "resConfUnit2.", others[1], nullptr, others[0], others[2], n, Hs[L], Ws[L]);
+      if (st) return st;
+      const int Ho = L > 0 ? Hs[L - 1] : 2 * Hs[0], Wo = L > 0 ? Ws[L - 1] : 2 * Ws[0];
+      LCHK(c, wm_launch_bilinear(others[2], others[0], n, Hs[L], Ws[L], Ho, Wo, F_, nullptr, nullptr, c.s));
+      st = conv(c, others[0], rp + "out_conv", true, nullptr, false, nullptr, others[1], n, Ho, Wo, 1, 1, 0, false);
+      if (st) return st;
+      cur = others[1];
+    }
+    const int H8 = 8 * gh, W8 = 8 * gw;
+    float* others[3];
+    {
+      int k = 0;
+      for (float* b : {S0, S1, S2, S3}) if (b != cur) others[k++] = b;
+    }
+    st = conv(c, cur, sc + "output_conv1", true, nullptr, false, nullptr, others[0], n, H8, W8, 3, 1, 1, false);
+    if (st) return st;
+    const int Ho = gh * cf.patch_size, Wo = gw * cf.patch_size;
+    float* fused = others[1];
+    LCHK(c, wm_launch_bilinear(others[0], fused, n, H8, W8, Ho, Wo, F_ / 2, B<float>(h, is_gs ? "gs_posx" : "dpt_posx"),
+                               B<float>(h, is_gs ? "gs_posy" : "dpt_posy"), c.s));
+    st = conv(c, fused, sc + "output_conv2.0", true, nullptr, false, nullptr, others[2], n, Ho, Wo, 3, 1, 1, false);
+    if (st) return st;
+    const size_t npix = (size_t)n * Ho * Wo, voff = (size_t)v0 * Ho * Wo;
+    LCHK(c, wm_launch_dpt_tail(others[2], F(h, sc + "output_conv2.2.weight"), F(h, sc + "output_conv2.2.bias"),
+                               out_attr + voff * (out_dim - 1), out_conf + voff, npix, out_dim, act, c.s));
+    (void)img; (void)gs_feat; (void)gs_params;
+  }
+  return WM_OK;
+}
+
+wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, int nt, int H, int W_, const float* pose7,
+                       const float* depth, const float* ray4, const int32_t* flags, const wm_outputs* out, hipStream_t s) {
+  if (!h || !img || !out) return WM_ERR_INVALID;
+  if (!h->finalized) return fail(h, WM_ERR_STATE, "weights not finalized");
+  const wm_config& cf = h->cfg;
+  if (n <= 0 || nt < n || nt % n) return fail(h, WM_ERR_INVALID, "n_total must be a positive multiple of n_local");
+  if (H % cf.patch_size || W_ % cf.patch_size) return fail(h, WM_ERR_INVALID, "H and W must be multiples of patch_size");
+  if (nt / n > 1 && (h->comm.kind == 0 || h->comm.world != nt / n)) return fail(h, WM_ERR_COMM, "communicator world size mismatch");
+  HIPCHK(h, hipSetDevice(h->device));
+  Ctx c{h, make_dims(h, n, nt, H, W_), s, cf.backbone_dtype, cf.head_dtype};
+  const Dims& d = c.d;
+  wm_status st = plan(h, d, s);
+  if (st) return st;
+  for (int k = 0; k < 5; ++k) h->ev_used[k] = 0;
+  ProfScope whole(h, 4, s);
+  const int D = d.D;
+  const std::string v = "visual_geometry_transformer.", dn = v + "patch_embed.";
+  float* Xd = B<float>(h, "Xd");
+  float* Xv = B<float>(h, "Xv");
+  void* A16 = B<void>(h, "A16");
+
+  // ---- a3/a4: normalise + patchify + DINOv2 encoder (vision_transformer.py:209-266)
+  LCHK(c, wm_launch_im2col(img, A16, n, 3, H, W_, cf.patch_size, d.kpad_patch, 1, c.bdt, s));
+  {
+    WmGemmArgs ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.rows_per_group = d.hw; ex.out_group = d.Td; ex.out_off = 1 + d.R; ex.add = B<float>(h, "dino_pos") + D;
+    st = gemm(c, c.bdt, WM_EPI_ROWMAP_ADD, A16, d.kpad_patch, W16(h, dn + "patch_embed.proj.weight"), d.kpad_patch, Xd, D,
+              F(h, dn + "patch_embed.proj.bias"), nullptr, n * d.hw, D, d.kpad_patch, &ex);
+    if (st) return st;
+  }
+  LCHK(c, wm_launch_dino_tokens(nullptr, F(h, dn + "cls_token"), F(h, dn + "register_tokens"), B<float>(h, "dino_pos"), Xd, n, d.hw, d.R, D, s));
+  for (int i = 0; i < cf.dino_depth; ++i) {
+    st = backbone_block(c, dn + "blocks." + std::to_string(i) + ".", Xd, d.Md, d.Td, cf.dino_heads, 1e-6f, false, false, d.Td, 0, false);
+    if (st) return st;
+  }
+  // final LN, patch tokens only, straight into the multi-view token buffer
+  st = layernorm(c, Xd, D, Xv, D, F(h, dn + "norm.weight"), F(h, dn + "norm.bias"), D, 1e-6f, n, d.hw, d.Td, 1 + d.R, d.P, d.psi, 1, 0);
+  if (st) return st;
+
+  // ---- a5: special + prior tokens (visual_transformer.py:285-295,343-371)
+  const float* pose_tok = nullptr; const float* ray_tok = nullptr;
+  if (cf.enable_cond) {
+    float* pin = B<float>(h, "pr_in"); float* ph = B<float>(h, "pr_h");
+    if (flags && flags[0] == 1 && pose7) {
+      LCHK(c, hipMemcpy2DAsync(pin, 8 * 4, pose7, 7 * 4, 7 * 4, n, hipMemcpyDeviceToDevice, s));
+      st = linear32(c, pin, 8, v + "pose_embed.0", ph, D, n, 0, 1);
+      if (st) return st;
+      st = linear32(c, ph, D, v + "pose_embed.2", B<float>(h, "pose_tok"), D, n, 0, 0);
+      if (st) return st;
+      pose_tok = B<float>(h, "pose_tok");
+    }
+    if (flags && flags[2] == 1 && ray4) {
+      st = linear32(c, ray4, 4, v + "ray_embed.0", ph, D, n, 0, 1);
+      if (st) return st;
+      st = linear32(c, ph, D, v + "ray_embed.2", B<float>(h, "ray_tok"), D, n, 0, 0);
+      if (st) return st;
+      ray_tok = B<float>(h, "ray_tok");
+    }
+    if (flags && flags[1] == 1 && depth) {  // PatchEmbed_Mlp (patch_embed.py:79-93): unshuffle -> fc1 -> GELU -> fc2, added to patches
+      LCHK(c, wm_launch_im2col(depth, A16, n, 1, H, W_, cf.patch_size, d.kpad_depth, 0, c.bdt, s));
+      void* H16 = B<void>(h, "H16");
+      st = gemm(c, c.bdt, WM_EPI_GELU_T16, A16, d.kpad_depth, W16(h, v + "depth_embed.proj.2.fc1.weight"), d.kpad_depth, H16, 4 * D,
+                F(h, v + "depth_embed.proj.2.fc1.bias"), nullptr, n * d.hw, 4 * D, d.kpad_depth);
+      if (st) return st;
+      WmGemmArgs ex;
+      memset(&ex, 0, sizeof(ex));
+      ex.rows_per_group = d.hw; ex.out_group = d.P; ex.out_off = d.psi; ex.accumulate = 1;
+      st = gemm(c, c.bdt, WM_EPI_ROWMAP_ADD, H16, 4 * D, W16(h, v + "depth_embed.proj.2.fc2.weight"), 4 * D, Xv, D,
+                F(h, v + "depth_embed.proj.2.fc2.bias"), nullptr, n * d.hw, D, 4 * D, &ex);
+      if (st) return st;
+    }
+  }
+  LCHK(c, wm_launch_vgt_special(Xv, F(h, v + "cam_token"), F(h, v + "reg_token"), pose_tok, ray_tok, n, d.P, d.R, D, cf.enable_cond, first_view, s));
+
+  // ---- a7-a10: 24 x (frame block, global block) + taps (visual_transformer.py:309-339)
+  int tap_i = 0;
+  for (int i = 0; i < cf.depth; ++i) {
+    st = backbone_block(c, v + "frame_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.P, cf.num_heads, 1e-5f, true, true, d.P, d.psi, false);
+    if (st) return st;
+    const bool is_tap = tap_i < 4 && i == cf.intermediate_idxs[tap_i];
+    float* tap = is_tap ? B<float>(h, ("tap" + std::to_string(tap_i)).c_str()) : nullptr;
+    if (is_tap) LCHK(c, wm_launch_copy2d(Xv, tap, d.Mv, D, D, 2 * D, s));
+    st = backbone_block(c, v + "global_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.Mv, cf.num_heads, 1e-5f, true, true, d.P, d.psi, true);
+    if (st) return st;
+    if (is_tap) {
+      LCHK(c, wm_launch_copy2d(Xv, tap + D, d.Mv, D, D, 2 * D, s));
+      if (out->taps[tap_i]) LCHK(c, hipMemcpyAsync(out->taps[tap_i], tap, (size_t)d.Mv * 2 * D * 4, hipMemcpyDeviceToDevice, s));
+      ++tap_i;
+    }
+  }
+
+  // ---- a11-a12: camera head
+  if (cf.enable_cam && out->camera_params) {
+    st = camera_head(c, B<float>(h, "cam_params"));
+    if (st) return st;
+    LCHK(c, hipMemcpyAsync(out->camera_params, B<float>(h, "cam_params"), (size_t)nt * 9 * 4, hipMemcpyDeviceToDevice, s));
+    if (out->camera_poses && out->camera_intrs)
+      LCHK(c, wm_launch_cam_matrices(B<float>(h, "cam_params"), out->camera_poses, out->camera_intrs, nt, H, W_, s));
+  }
+  // ---- a13: DPT heads (worldmirror.py:74-98)
+  if (cf.enable_depth && out->depth && out->depth_conf) {
+    st = dpt_head(c, "depth_head.", cf.dpt_features, 2, WM_ACT_EXP, false, out->depth, out->depth_conf, img, nullptr, nullptr);
+    if (st) return st;
+  }
+  if (cf.enable_pts && out->pts3d && out->pts3d_conf) {
+    st = dpt_head(c, "pts_head.", cf.dpt_features, 4, WM_ACT_INV_LOG, false, out->pts3d, out->pts3d_conf, img, nullptr, nullptr);
+    if (st) return st;
+  }
+  if (cf.enable_norm && out->normals && out->normals_conf) {
+    st = dpt_head(c, "norm_head.", cf.dpt_features, 4, WM_ACT_NORM, false, out->normals, out->normals_conf, img, nullptr, nullptr);
+    if (st) return st;
+  }
+  if (cf.enable_gs && out->gs_depth && out->gs_depth_conf) {
+    st = dpt_head(c, "gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf, img, out->gs_feat, out->gs_params);
+    if (st) return st;
+  }
+  return WM_OK;
+}
+
+}  // namespace
+
+extern "C" wm_status wm_forward(wm_handle* h, const float* img, int N, int H, int W, const float* pose7, const float* depth,
+                                const float* ray4, const int32_t cond_flags[3], const wm_outputs* out, void* stream) {
+  return forward_impl(h, img, N, 0, N, H, W, pose7, depth, ray4, cond_flags, out, (hipStream_t)stream);
+}
+
+extern "C" wm_status wm_forward_sharded(wm_handle* h, const float* img, int n_local, int first_view, int n_total, int H, int W,
+                                        const float* pose7, const float* depth, const float* ray4, const int32_t cond_flags[3],
+                                        const wm_outputs* out, void* stream) {
+  return forward_impl(h, img, n_local, first_view, n_total, H, W, pose7, depth, ray4, cond_flags, out, (hipStream_t)stream);
+}
+
+// ====================================================================================== communicator
+extern "C" wm_status wm_rccl_unique_id(uint8_t id[WM_RCCL_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= WM_RCCL_ID_BYTES, "id buffer too small");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return WM_ERR_COMM;
+  memset(id, 0, WM_RCCL_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return WM_OK;
+}
+
+extern "C" wm_status wm_comm_init_rccl(wm_handle* h, const uint8_t id[WM_RCCL_ID_BYTES], int rank, int world) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return WM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  if (ncclCommInitRank(&h->comm.nccl, world, u, rank) != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclCommInitRank failed");
+  h->comm.kind = 1; h->comm.rank = rank; h->comm.world = world;
+  return WM_OK;
+}
+
+extern "C" wm_local_group* wm_local_group_create(int world) {
+  wm_local_group* g = new wm_local_group();
+  g->world = world;
+  g->recv.assign(world, nullptr);
+  pthread_barrier_init(&g->bar, nullptr, world);
+  return g;
+}
+extern "C" void wm_local_group_destroy(wm_local_group* g) {
+  if (!g) return;
+  pthread_barrier_destroy(&g->bar);
+  delete g;
+}
+extern "C" wm_status wm_comm_init_local(wm_handle* h, wm_local_group* g, int rank) {
+  if (!h || !g || rank < 0 || rank >= g->world) return WM_ERR_INVALID;
+  h->comm.kind = 2; h->comm.rank = rank; h->comm.world = g->world; h->comm.grp = g;
+  return WM_OK;
+}
+
+// ====================================================================================== profiling
+extern "C" wm_status wm_profile_enable(wm_handle* h, int on) {
+  if (!h) return WM_ERR_INVALID;
+  h->prof = on != 0;
+  return WM_OK;
+}
+extern "C" wm_status wm_profile_read(wm_handle* h, int kind, double* total_ms, int64_t* launches) {
+  if (!h || kind < 0 || kind > 4) return WM_ERR_INVALID;
+  double tot = 0;
+  for (size_t i = 0; i < h->ev_used[kind]; ++i) {
+    float ms = 0;
+    HIPCHK(h, hipEventSynchronize(h->ev[kind][i].b));
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[kind][i].a, h->ev[kind][i].b));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)h->ev_used[kind];
+  return WM_OK;
+}
+
+// ====================================================================================== operator-level entry points
+extern "C" wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* Wp, void* C, const float* bias, const float* gamma,
+                                int M, int N, int K, void* stream) {
+  WmGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.W = Wp; a.C = C; a.bias = bias; a.gamma = gamma; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N;
+  a.dtype = dtype; a.epi = epi;
+  return wm_launch_gemm(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
+                                     int kv_chunks, int kv_rows_per_chunk, void* stream) {
+  WmAttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.H = H; a.q_rows = q_rows; a.seq_len = seq_len; a.q_head_stride = q_rows;
+  a.kv_chunks = kv_chunks; a.dtype = dtype;
+  if (kv_chunks > 1) {
+    a.kv_head_stride = kv_rows_per_chunk; a.kv_rows_per_chunk = kv_rows_per_chunk; a.kv_chunk_stride = (long long)H * kv_rows_per_chunk * 64;
+  } else {
+    a.kv_head_stride = q_rows;
+  }
+  return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_layernorm(const float* x, void* y, const float* w, const float* b, int rows, int D, float eps, int out_f32,
+                                     int dtype, void* stream) {
+  WmLnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.w = w; a.b = b; a.D = D; a.ld_in = D; a.ld_out = D; a.eps = eps; a.groups = 1; a.rows_per_group = rows;
+  a.out_f32 = out_f32; a.dtype = dtype;
+  return wm_launch_layernorm(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_qkv_post(int dtype, const float* qkv, void* q, void* k, void* v, const float* qn_w, const float* qn_b,
+                                    const float* kn_w, const float* kn_b, const float* rope_cos, const float* rope_sin, int M, int H,
+                                    int tokens_per_view, int patch_start, int grid_w, float q_scale, void* stream) {
+  WmQkvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.qkv = qkv; a.q = q; a.k = k; a.v = v; a.qn_w = qn_w; a.qn_b = qn_b; a.kn_w = kn_w; a.kn_b = kn_b; a.rope_cos = rope_cos; a.rope_sin = rope_sin;
+  a.M = M; a.H = H; a.head_stride = M; a.tokens_per_view = tokens_per_view; a.patch_start = patch_start; a.grid_w = grid_w; a.q_scale = q_scale;
+  a.dtype = dtype;
+  return wm_launch_qkv_post(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_conv(int dtype, const float* x, const void* w16, const float* bias, const float* resid, const float* resid2,
+                                float* y, int N, int Hi, int Wi, int Cin, int Cout, int ksize, int stride, int pad, int relu_in,
+                                int resid_relu, void* stream) {
+  WmConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w16; a.bias = bias; a.resid = resid; a.resid2 = resid2; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
+  a.ksize = ksize; a.stride = stride; a.pad = pad; a.Ho = (Hi + 2 * pad - ksize) / stride + 1; a.Wo = (Wi + 2 * pad - ksize) / stride + 1;
+  a.relu_in = relu_in; a.resid_relu = resid_relu; a.dtype = dtype;
+  return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
+  return wm_launch_bilinear(in, out, N, Hi, Wi, Ho, Wo, C, nullptr, nullptr, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_linear_f32(const float* X, const float* Wp, const float* b, float* Y, int M, int N, int K, int ldx, int pre_act,
+                                      int post_act, void* stream) {
+  return wm_launch_linear_f32(X, Wp, b, Y, M, N, K, ldx, N, pre_act, post_act, nullptr, 0, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}

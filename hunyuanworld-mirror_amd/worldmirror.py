@@ -1,0 +1,346 @@
+"""Host-side mirror of the reference's model API (src/models/models/worldmirror.py:16-251).
+
+``WorldMirror`` keeps the reference's constructor kwargs, ``from_pretrained(dir)``, ``.to()``,
+``.eval()`` and ``__call__(views, cond_flags)`` so that the reference's infer.py / app.py only need
+their import line changed.  Everything between the input dict and the output dict
+runs in libwm_hip.so (hand-written HIP for gfx950) through the C ABI of include/wm_hip.h; torch is
+used for device memory, the current stream and the torch.distributed rendezvous only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import WMConfig, param_spec
+from .weights import iter_params
+
+
+# ------------------------------------------------------------------------------------------------
+# a2: prior normalisation (worldmirror.py:218-251, utils/priors.py, utils/rotation.py) — tiny,
+# cross-view statistics; computed once on the full view set before sharding.
+# ------------------------------------------------------------------------------------------------
+def _rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:  # rotation.py:41-97 (xyzw, w >= 0)
+    m = R.reshape(R.shape[:-2] + (9,))
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.unbind(-1)
+    t = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1)
+    q_abs = torch.where(t > 0, torch.sqrt(t.clamp(min=0)), torch.zeros_like(t))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    idx = q_abs.argmax(-1)
+    out = torch.gather(cand, -2, idx[..., None, None].expand(idx.shape + (1, 4))).squeeze(-2)
+    out = out[..., [1, 2, 3, 0]]
+    return torch.where(out[..., 3:4] < 0, -out, out)
+
+
+def _normalize_poses(ext: torch.Tensor, padding: float = 0.1) -> torch.Tensor:  # priors.py:4-105
+    ext = torch.nan_to_num(ext.clone(), nan=0.0, posinf=1e6, neginf=-1e6)
+    out = ext.clone()
+    for b in range(ext.shape[0]):
+        pos = ext[b, :, :3, 3]
+        if pos.shape[0] > 10:
+            lo, hi = torch.quantile(pos, 0.05, dim=0), torch.quantile(pos, 0.95, dim=0)
+        else:
+            lo, hi = pos.min(0)[0], pos.max(0)[0]
+        rng = torch.maximum(hi - lo, torch.maximum(torch.full_like(hi, 1e-6), hi.abs() * 1e-6))
+        scale = rng.max().clamp(1e-6, 1e6)
+        out[b, :, :3, 3] = ((pos - (lo + hi) / 2) / (scale / (1 - 2 * padding)) + 0.5).clamp(0, 1)
+    return out
+
+
+def _normalize_depth(depth: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:  # priors.py:108-167
+    B, S, H, W = depth.shape
+    d = torch.nan_to_num(depth.reshape(B * S, H, W), nan=0.0, posinf=1e6, neginf=0.0)
+    outs = []
+    for i in range(B * S):
+        flat = d[i].flatten()
+        use = flat[flat > 0] if bool((flat > 0).any()) else flat
+        if use.numel() > 100:
+            lo, hi = torch.quantile(use, 0.01), torch.quantile(use, 0.99)
+        else:
+            lo, hi = use.min(), use.max()
+        if bool(hi == lo):
+            hi = lo + 1.0
+        e = max(eps, float((hi - lo).abs()) * eps)
+        outs.append(((d[i] - lo) / (hi - lo + e)).clamp(0, 1))
+    return torch.stack(outs).reshape(B, S, H, W)
+
+
+def extract_priors(views: Dict[str, torch.Tensor]):
+    """(depths [B,S,H,W], rays [B,S,4], poses [B,S,7]) exactly as worldmirror.py:218-251."""
+    h, w = views["img"].shape[-2:]
+    depths = rays = poses = None
+    if "camera_pose" in views:
+        ext = _normalize_poses(views["camera_pose"][:, :, :3].float())
+        poses = torch.cat([ext[..., :3, 3], _rotmat_to_quat(ext[..., :3, :3])], -1).float()
+    if "depthmap" in views:
+        depths = _normalize_depth(views["depthmap"].float())
+    if "camera_intrinsics" in views:
+        K = views["camera_intrinsics"][:, :, :3, :3].float()
+        rays = torch.stack([K[..., 0, 0] / w, K[..., 1, 1] / h, K[..., 0, 2] / w, K[..., 1, 2] / h], -1)
+    return depths, rays, poses
+
+
+class _GSRendererStub:
+    """Placeholder for ``model.gs_renderer`` (infer.py:264): rasterisation is out of scope."""
+
+    def __getattr__(self, name):
+        raise NotImplementedError("gsplat rasterisation is stubbed in the MI355X build (BASELINE config 5)")
+
+
+class WorldMirror:
+    """Drop-in for the reference WorldMirror (ctor kwargs: worldmirror.py:17-34)."""
+
+    def __init__(self, img_size=518, patch_size=14, embed_dim=1024, gs_dim=256, enable_cond=True, enable_cam=True,
+                 enable_pts=True, enable_depth=True, enable_norm=True, enable_gs=True,
+                 patch_embed="dinov2_vitl14_reg", fixed_patch_embed=False, sampling_strategy="uniform",
+                 dpt_gradient_checkpoint=False, condition_strategy=("token", "pow3r", "token"),
+                 enable_interpolation=False, max_resolution=2044, *, dtype="bf16", head_dtype="f16",
+                 arch: Optional[WMConfig] = None):
+        # accepted and ignored, as they are inert at inference in the reference
+        del fixed_patch_embed, sampling_strategy, dpt_gradient_checkpoint, enable_interpolation, max_resolution
+        if list(condition_strategy) != ["token", "pow3r", "token"]:
+            raise NotImplementedError("only condition_strategy=['token','pow3r','token'] exists in the reference")
+        if arch is None:
+            if patch_embed != "dinov2_vitl14_reg":
+                raise NotImplementedError("reference checkpoints use patch_embed='dinov2_vitl14_reg'")
+            arch = WMConfig(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, gs_dim=gs_dim,
+                            enable_cond=enable_cond, enable_cam=enable_cam, enable_pts=enable_pts,
+                            enable_depth=enable_depth, enable_norm=enable_norm, enable_gs=enable_gs)
+        self.cfg = arch
+        self.dtype, self.head_dtype = dtype, head_dtype
+        self.enable_cam, self.enable_pts = arch.enable_cam, arch.enable_pts
+        self.enable_depth, self.enable_norm, self.enable_gs = arch.enable_depth, arch.enable_norm, arch.enable_gs
+        self.gs_renderer = _GSRendererStub()
+        self._host_weights: Dict[str, np.ndarray] = {}
+        self._handle = None
+        self._device: Optional[torch.device] = None
+        self._comm = None  # (rank, world)
+        self.training = False
+        self.return_taps = False
+
+    # ------------------------------------------------------------------ weights
+    @classmethod
+    def from_pretrained(cls, path: str, **kw):
+        """Local directory with config.json + model.safetensors (huggingface_hub mixin layout)."""
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path}: only local checkpoints are supported (no network)")
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        m = cls(**{**cfg, **kw})
+        from safetensors import safe_open
+        sd = {}
+        with safe_open(os.path.join(path, "model.safetensors"), framework="np") as f:
+            for k in f.keys():
+                sd[k] = f.get_tensor(k)
+        m.load_state_dict(sd, strict=False)
+        return m
+
+    def load_state_dict(self, sd, strict: bool = False):
+        spec = param_spec(self.cfg)
+        missing = [k for k in spec if k not in sd]
+        unexpected = [k for k in sd if k not in spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"missing {missing[:5]} unexpected {unexpected[:5]}")
+        for k, v in sd.items():
+            if k in spec:
+                a = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)
+                if tuple(a.shape) != tuple(spec[k]):
+                    raise RuntimeError(f"shape mismatch for {k}: {a.shape} vs {spec[k]}")
+                self._host_weights[k] = np.ascontiguousarray(a)
+        if self._handle is not None:
+            self._upload()
+        return missing, unexpected
+
+    def init_synthetic_weights(self, seed: int = 0):
+        """Deterministic name-keyed weights (weights.py) — what parity tests and bench.py use."""
+        if self._handle is not None:
+            self._upload(iter_params(self.cfg, seed))
+        else:
+            self._host_weights = dict(iter_params(self.cfg, seed))
+        return self
+
+    def _err(self) -> str:
+        return _lib.lib().wm_last_error(self._handle).decode()
+
+    def _upload(self, it=None):
+        L = _lib.lib()
+        items = it if it is not None else self._host_weights.items()
+        for k, a in items:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            st = L.wm_set_weight(self._handle, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+            if st != 0:
+                raise RuntimeError(f"wm_set_weight({k}): {self._err()}")
+        miss = C.c_int(0)
+        if L.wm_finalize_weights(self._handle, C.byref(miss)) != 0:
+            raise RuntimeError(f"wm_finalize_weights: {self._err()}")
+        self.missing_weights = miss.value
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the MI355X build has no CPU path: move the model to a 'cuda' (HIP) device")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        L = _lib.lib()
+        if self._handle is not None:
+            L.wm_destroy(self._handle)
+        cfg = _lib.make_config(self.cfg, self.dtype, self.head_dtype)
+        h = C.c_void_p()
+        st = L.wm_create(C.byref(cfg), idx, C.byref(h))
+        self._handle = h
+        if st != 0:
+            raise RuntimeError(f"wm_create: {self._err()}")
+        self._device = torch.device("cuda", idx)
+        self._upload()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().wm_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ multi-GPU
+    def shard(self, group=None):
+        """View-shard across the ranks of a torch.distributed group (one process per GPU): creates
+        the handle's own RCCL communicator from an id broadcast through ``group``."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        L = _lib.lib()
+        buf = (C.c_uint8 * 128)()
+        if rank == 0 and L.wm_rccl_unique_id(buf) != 0:
+            raise RuntimeError("wm_rccl_unique_id failed")
+        dev = self._device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ids = (C.c_uint8 * 128)(*t.cpu().tolist())
+        if L.wm_comm_init_rccl(self._handle, ids, rank, world) != 0:
+            raise RuntimeError(f"wm_comm_init_rccl: {self._err()}")
+        self._comm = (rank, world)
+        return self
+
+    def shard_local(self, group_ptr, rank: int, world: int):
+        """In-process rank group (tests): see wm_comm_init_local."""
+        if _lib.lib().wm_comm_init_local(self._handle, group_ptr, rank) != 0:
+            raise RuntimeError(f"wm_comm_init_local: {self._err()}")
+        self._comm = (rank, world)
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, views: Dict[str, torch.Tensor], cond_flags: List[int] = [0, 0, 0]):
+        return self.forward(views, cond_flags)
+
+    @torch.no_grad()
+    def forward(self, views: Dict[str, torch.Tensor], cond_flags: List[int] = [0, 0, 0]):
+        if self._handle is None:
+            raise RuntimeError("call .to('cuda') first: the forward pass runs in libwm_hip.so on the GPU")
+        L = _lib.lib()
+        dev = self._device
+        imgs = views["img"]
+        if imgs.dim() != 5 or imgs.shape[0] != 1:
+            raise ValueError("views['img'] must be [1, S, 3, H, W] (B is always 1 at inference, infer.py:143)")
+        _, S, ch, H, W = imgs.shape
+        if ch != 3:
+            raise ValueError(f"Expected 3 input channels, got {ch}")  # visual_transformer.py:272-273
+        ps = self.cfg.patch_size
+        assert H % ps == 0, f"Input image height {H} is not a multiple of patch height {ps}"  # patch_embed.py:67-68
+        assert W % ps == 0, f"Input image width {W} is not a multiple of patch width: {ps}"
+        flags = [int(x) for x in cond_flags]
+        depths = rays = poses = None
+        if sum(flags) > 0:  # worldmirror.py:134-141
+            depths, rays, poses = extract_priors(views)
+        rank, world = self._comm if self._comm else (0, 1)
+        if S % world:
+            raise ValueError(f"{S} views do not shard evenly over {world} ranks")
+        n = S // world
+        v0 = rank * n
+
+        def local(t, shape):
+            if t is None:
+                return None
+            return t[0, v0:v0 + n].to(dev, torch.float32).reshape(shape).contiguous()
+        img_l = local(imgs, (n, 3, H, W))
+        pose_l = local(poses, (n, 7))
+        ray_l = local(rays, (n, 4))
+        depth_l = local(depths, (n, H, W))
+
+        o = _lib.wm_outputs()
+        res: Dict[str, torch.Tensor] = {}
+
+        def alloc(key, field, shape):
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+            res[key] = t
+            setattr(o, field, t.data_ptr())
+        if self.cfg.enable_cam:
+            alloc("camera_params", "camera_params", (1, S, 9))
+            alloc("camera_poses", "camera_poses", (1, S, 4, 4))
+            alloc("camera_intrs", "camera_intrs", (1, S, 3, 3))
+        if self.cfg.enable_depth:
+            alloc("depth", "depth", (1, n, H, W, 1))
+            alloc("depth_conf", "depth_conf", (1, n, H, W))
+        if self.cfg.enable_pts:
+            alloc("pts3d", "pts3d", (1, n, H, W, 3))
+            alloc("pts3d_conf", "pts3d_conf", (1, n, H, W))
+        if self.cfg.enable_norm:
+            alloc("normals", "normals", (1, n, H, W, 3))
+            alloc("normals_conf", "normals_conf", (1, n, H, W))
+        if self.cfg.enable_gs:
+            alloc("gs_depth", "gs_depth", (1, n, H, W, 1))
+            alloc("gs_depth_conf", "gs_depth_conf", (1, n, H, W))
+            alloc("gs_feat", "gs_feat", (1, n, H, W, self.cfg.gs_dim // 2))
+            alloc("gs_params", "gs_params", (1, n, H, W, 12))
+        taps = None
+        if self.return_taps:
+            P = self.cfg.patch_start_idx + (H // ps) * (W // ps)
+            taps = [torch.empty((1, n, P, 2 * self.cfg.embed_dim), dtype=torch.float32, device=dev) for _ in range(4)]
+            for i in range(4):
+                o.taps[i] = taps[i].data_ptr()
+        fl = (C.c_int32 * 3)(*flags)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if world == 1:
+            st = L.wm_forward(self._handle, _lib.ptr(img_l), n, H, W, _lib.ptr(pose_l), _lib.ptr(depth_l), _lib.ptr(ray_l),
+                              fl, C.byref(o), stream)
+        else:
+            st = L.wm_forward_sharded(self._handle, _lib.ptr(img_l), n, v0, S, H, W, _lib.ptr(pose_l), _lib.ptr(depth_l),
+                                      _lib.ptr(ray_l), fl, C.byref(o), stream)
+        if st != 0:
+            raise RuntimeError(f"wm_forward failed ({st}): {self._err()}")
+        if taps is not None:
+            res["taps"] = taps
+        self._keepalive = (img_l, pose_l, ray_l, depth_l)
+        return res
+
+    # ------------------------------------------------------------------ profiling hooks (bench.py)
+    def profile(self, on: bool):
+        _lib.lib().wm_profile_enable(self._handle, 1 if on else 0)
+
+    def profile_read(self, kind: int):
+        ms, n = C.c_double(0), C.c_int64(0)
+        if _lib.lib().wm_profile_read(self._handle, kind, C.byref(ms), C.byref(n)) != 0:
+            raise RuntimeError(self._err())
+        return ms.value, n.value

@@ -1,0 +1,124 @@
+/* libwm_hip.so — C ABI of the MI355X-native WorldMirror forward pass.
+ *
+ * The reference (zubair-irshad/HunyuanWorld-Mirror) has no FFI/operator layer on this path: its
+ * boundary is the Python class WorldMirror (src/models/models/worldmirror.py:16) whose forward()
+ * (:120-152) is pure torch.nn.  This header is the boundary a maintainer binds instead (ctypes stub
+ * in INTEGRATION.md); each entry cites the reference call it replaces.  Plain pointers and sizes
+ * only; device pointers are HIP device memory owned by the caller (torch-ROCm tensors in practice).
+ *
+ * Threading: one handle per (process, device); calls on a handle are serialised by the caller and
+ * are stream-ordered on the hipStream_t passed in (hipStream_t is passed as void*).
+ */
+#ifndef WM_HIP_H
+#define WM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wm_handle wm_handle;
+
+typedef enum { WM_OK = 0, WM_ERR_INVALID = 1, WM_ERR_HIP = 2, WM_ERR_STATE = 3, WM_ERR_COMM = 4 } wm_status;
+typedef enum { WM_DT_BF16 = 0, WM_DT_F16 = 1 } wm_dtype;
+
+/* Architecture: reference ctor kwargs (worldmirror.py:17-34) + the sub-module defaults they imply
+ * (visual_transformer.py:48-70, vision_transformer.py:364-375, camera_head.py:16-27,
+ * dense_head.py:34-46). */
+typedef struct {
+  int32_t img_size, patch_size, embed_dim, gs_dim;
+  int32_t enable_cond, enable_cam, enable_pts, enable_depth, enable_norm, enable_gs;
+  int32_t depth, num_heads, mlp_ratio, num_register_tokens;
+  int32_t intermediate_idxs[4];
+  float rope_freq;
+  int32_t dino_depth, dino_heads;
+  int32_t cam_trunk_depth, cam_heads, cam_steps;
+  int32_t dpt_features;
+  int32_t dpt_out_channels[4];
+  int32_t backbone_dtype; /* wm_dtype of GEMM/attention operands inside the backbone (reference GPU recipe: bf16) */
+  int32_t head_dtype;     /* wm_dtype of DPT conv operands (fp32 accumulate/activations; default f16)          */
+} wm_config;
+
+/* Outputs of WorldMirror.forward (worldmirror.py:157-216), caller-allocated f32 device buffers for
+ * the LOCAL views; any pointer may be NULL to skip that output (a NULL dense output skips its head). */
+typedef struct {
+  float* camera_params; /* [N_total][9]  (camera head attends across all views) */
+  float* camera_poses;  /* [N_total][4][4] c2w */
+  float* camera_intrs;  /* [N_total][3][3] */
+  float* depth;         /* [N][H][W][1] */
+  float* depth_conf;    /* [N][H][W]    */
+  float* pts3d;         /* [N][H][W][3] */
+  float* pts3d_conf;    /* [N][H][W]    */
+  float* normals;       /* [N][H][W][3] */
+  float* normals_conf;  /* [N][H][W]    */
+  float* gs_depth;      /* [N][H][W][1] */
+  float* gs_depth_conf; /* [N][H][W]    */
+  float* gs_feat;       /* [N][H][W][gs_dim/2] NHWC fused GS feature (dense_head.py:232-244) */
+  float* gs_params;     /* [N][H][W][12] raw gaussian parameters (rasterization.py:149-153)  */
+  float* taps[4];       /* optional: the 4 backbone taps [N][P][2*D] (visual_transformer.py:337-339) */
+} wm_outputs;
+
+/* ---- lifecycle (replaces WorldMirror.__init__ / from_pretrained / load_state_dict) ---- */
+wm_status wm_create(const wm_config* cfg, int device, wm_handle** out);
+void wm_destroy(wm_handle* h);
+const char* wm_last_error(const wm_handle* h);
+/* One reference state_dict tensor (fp32, host memory). Unknown names are ignored (strict=False). */
+wm_status wm_set_weight(wm_handle* h, const char* name, const float* host, const int64_t* shape, int ndim);
+/* Number of spec'd parameters still missing is written to *missing (strict=False: missing stay zero). */
+wm_status wm_finalize_weights(wm_handle* h, int* missing);
+/* DINO pos-embed resample for a non-native grid is done inside the library (host, once per shape);
+ * exported for tests: in [gs*gs][D] -> out [gh*gw][D], bicubic antialias (vision_transformer.py:175-207). */
+void wm_host_resample_pos(const float* in, int gs, int D, int gh, int gw, float* out);
+
+/* ---- forward (replaces WorldMirror.forward, worldmirror.py:120-152) ---- */
+size_t wm_workspace_bytes(const wm_handle* h, int n_local, int n_total, int H, int W);
+/* img [N][3][H][W] f32 in [0,1]; priors already normalised as extract_priors returns them
+ * (worldmirror.py:218-251): pose7 [N][7], depth [N][H][W], ray4 [N][4]; any may be NULL.
+ * cond_flags = [pose, depth, rays]. */
+wm_status wm_forward(wm_handle* h, const float* img, int N, int H, int W, const float* pose7, const float* depth,
+                     const float* ray4, const int32_t cond_flags[3], const wm_outputs* out, void* stream);
+/* View-sharded forward: this rank owns views [first_view, first_view + n_local) of n_total; K/V of
+ * every global-attention layer and the camera tokens are all-gathered through the handle's comm. */
+wm_status wm_forward_sharded(wm_handle* h, const float* img, int n_local, int first_view, int n_total, int H, int W,
+                             const float* pose7, const float* depth, const float* ray4, const int32_t cond_flags[3],
+                             const wm_outputs* out, void* stream);
+
+/* ---- communicator for the sharded path ---- */
+#define WM_RCCL_ID_BYTES 128
+wm_status wm_rccl_unique_id(uint8_t id[WM_RCCL_ID_BYTES]);
+wm_status wm_comm_init_rccl(wm_handle* h, const uint8_t id[WM_RCCL_ID_BYTES], int rank, int world);
+/* In-process group (ranks = host threads, one handle each, possibly sharing one GPU): used by tests. */
+typedef struct wm_local_group wm_local_group;
+wm_local_group* wm_local_group_create(int world);
+void wm_local_group_destroy(wm_local_group* g);
+wm_status wm_comm_init_local(wm_handle* h, wm_local_group* g, int rank);
+
+/* ---- timing hooks used by bench.py: HIP events on the launch stream around kernel classes ---- */
+/* kind: 0 = global attention, 1 = frame+dino attention, 2 = GEMM, 3 = DPT conv, 4 = whole forward */
+wm_status wm_profile_enable(wm_handle* h, int on);
+wm_status wm_profile_read(wm_handle* h, int kind, double* total_ms, int64_t* launches);
+
+/* ---- operator-level entry points (device pointers) used by the parity tests ---- */
+wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, const float* gamma,
+                     int M, int N, int K, void* stream);
+wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
+                          int kv_chunks, int kv_rows_per_chunk, void* stream);
+wm_status wm_op_layernorm(const float* x, void* y, const float* w, const float* b, int rows, int D, float eps, int out_f32,
+                          int dtype, void* stream);
+wm_status wm_op_qkv_post(int dtype, const float* qkv, void* q, void* k, void* v, const float* qn_w, const float* qn_b,
+                         const float* kn_w, const float* kn_b, const float* rope_cos, const float* rope_sin, int M, int H,
+                         int tokens_per_view, int patch_start, int grid_w, float q_scale, void* stream);
+wm_status wm_op_conv(int dtype, const float* x, const void* w16, const float* bias, const float* resid, const float* resid2,
+                     float* y, int N, int Hi, int Wi, int Cin, int Cout, int ksize, int stride, int pad, int relu_in,
+                     int resid_relu, void* stream);
+wm_status wm_op_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
+wm_status wm_op_linear_f32(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int ldx, int pre_act,
+                           int post_act, void* stream);
+/* host helper: fp32 -> 16-bit (round to nearest even), for building test operands */
+void wm_host_to_16(const float* in, uint16_t* out, size_t n, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library loads, exports every symbol include/wm_hip.h declares, and its host-side
+helpers (no GPU needed) match torch: bicubic-antialias pos-embed resample, 16-bit rounding."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+LIB = os.path.join(ROOT, "hunyuanworld-mirror_amd", "libwm_hip.so")
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    return C.CDLL(LIB)
+
+
+def test_exports_match_header(L):
+    hdr = open(os.path.join(ROOT, "include", "wm_hip.h")).read()
+    names = set(re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"wm_status"}
+    from hunyuanworld_mirror_amd import _lib
+    assert names == set(_lib.EXPORTS), names ^ set(_lib.EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_config_struct_layout_matches_header():
+    from hunyuanworld_mirror_amd import _lib
+    assert C.sizeof(_lib.wm_config) == 4 * (4 + 6 + 4 + 4 + 1 + 2 + 3 + 1 + 4 + 2)
+    assert C.sizeof(_lib.wm_outputs) == 8 * 17
+
+
+@pytest.mark.parametrize("gh,gw", [(5, 4), (4, 5), (3, 3), (16, 16), (7, 5)])
+def test_host_pos_resample_matches_torch(L, gh, gw):
+    gs, D = 5, 8
+    g = torch.Generator().manual_seed(gh * 10 + gw)
+    src = torch.randn(gs * gs, D, generator=g)
+    out = np.empty((gh * gw, D), np.float32)
+    L.wm_host_resample_pos.restype = None
+    L.wm_host_resample_pos(C.c_void_p(src.numpy().ctypes.data), gs, D, gh, gw, C.c_void_p(out.ctypes.data))
+    ref = torch.nn.functional.interpolate(src.reshape(1, gs, gs, D).permute(0, 3, 1, 2), size=(gh, gw), mode="bicubic",
+                                          antialias=True).permute(0, 2, 3, 1).reshape(gh * gw, D)
+    assert np.abs(out - ref.numpy()).max() < 2e-6
+
+
+def test_host_to_16(L):
+    x = torch.randn(1000) * 100
+    x[0], x[1], x[2] = float("nan"), float("inf"), 0.0
+    out = np.empty(1000, np.uint16)
+    L.wm_host_to_16.restype = None
+    for dt, tdt in ((0, torch.bfloat16), (1, torch.float16)):
+        L.wm_host_to_16(C.c_void_p(x.numpy().ctypes.data), C.c_void_p(out.ctypes.data), C.c_size_t(1000), dt)
+        ref = x.to(tdt).view(torch.int16).numpy().view(np.uint16)
+        ok = (out == ref) | (np.isnan(x.numpy()))
+        assert ok.all()
+        assert np.isnan(torch.from_numpy(out.view(np.int16)).view(tdt).float()[0])
+
+
+def test_product_path_has_no_cpu_fallback():
+    from hunyuanworld_mirror_amd import WorldMirror, WMConfig
+    m = WorldMirror(arch=WMConfig.tiny())
+    with pytest.raises(RuntimeError):
+        m.to("cpu")
+    with pytest.raises(RuntimeError):
+        m({"img": torch.rand(1, 1, 3, 70, 70)})
+
+
+def test_param_spec_counts():
+    from hunyuanworld_mirror_amd import WMConfig, param_spec
+    n = sum(int(np.prod(s)) for s in param_spec(WMConfig()).values())
+    assert abs(n - 1.230e9) / 1.230e9 < 2e-3          # 1.230 B parameters without GS
+    n_gs = sum(int(np.prod(s)) for s in param_spec(WMConfig(enable_gs=True)).values())
+    assert abs(n_gs - 1.263e9) / 1.263e9 < 2e-3

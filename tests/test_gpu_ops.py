@@ -1,0 +1,267 @@
+"""GPU: operator-level parity of the HIP kernels, called through the C ABI (wm_op_*), against plain
+torch fp32 references evaluated on the SAME 16-bit-rounded operands.  Tolerances are stated per test:
+MFMA accumulates in fp32, so the only differences are summation order and the 16-bit output rounding.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F16 = 0, 1
+
+
+def _lib():
+    from hunyuanworld_mirror_amd import _lib
+    return _lib.lib()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _t16(x, dt):
+    return x.to(torch.bfloat16 if dt == BF16 else torch.float16)
+
+
+def _from16(buf, dt):
+    return buf.view(torch.bfloat16 if dt == BF16 else torch.float16).float()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 384, 640), (2752, 1024, 1024), (77, 64, 64), (1376, 4096, 1024)])
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_gemm_epilogues(dev, M, N, K, dt):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    A = _t16(torch.randn(M, K, generator=g), dt).to(dev)
+    W = _t16(torch.randn(N, K, generator=g) / math.sqrt(K), dt).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    gamma = torch.randn(N, generator=g).to(dev)
+    ref = A.float() @ W.float().t() + bias
+    L = _lib()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # EPI 0: f32
+    out = torch.empty(M, N, device=dev)
+    assert L.wm_op_gemm(dt, 0, _p(A), _p(W), _p(out), _p(bias), None, M, N, K, s) == 0
+    torch.cuda.synchronize()
+    e = _rel(out, ref)
+    print(f"gemm f32 {M}x{N}x{K} dt{dt}: {e:.2e}")
+    assert e < 2e-5
+    # EPI 1: 16-bit out
+    o16 = torch.empty(M, N, device=dev, dtype=torch.int16)
+    assert L.wm_op_gemm(dt, 1, _p(A), _p(W), _p(o16), _p(bias), None, M, N, K, s) == 0
+    torch.cuda.synchronize()
+    assert _rel(_from16(o16, dt), ref) < (6e-3 if dt == BF16 else 8e-4)
+    # EPI 2: GELU(erf) 16-bit
+    assert L.wm_op_gemm(dt, 2, _p(A), _p(W), _p(o16), _p(bias), None, M, N, K, s) == 0
+    torch.cuda.synchronize()
+    assert _rel(_from16(o16, dt), torch.nn.functional.gelu(ref)) < (6e-3 if dt == BF16 else 8e-4)
+    # EPI 3: X += gamma * (acc + bias)
+    X0 = torch.randn(M, N, generator=g).to(dev)
+    X = X0.clone()
+    assert L.wm_op_gemm(dt, 3, _p(A), _p(W), _p(X), _p(bias), _p(gamma), M, N, K, s) == 0
+    torch.cuda.synchronize()
+    assert _rel(X, X0 + gamma * ref) < 2e-5
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I with an asymmetric W catches a transposed C-write (guides §3)."""
+    K = N = 128
+    A = torch.eye(K).to(torch.bfloat16).to(dev)
+    W = (torch.arange(N)[:, None] * 2.0 + torch.arange(K)[None, :] * 0.25).to(torch.bfloat16).to(dev)
+    out = torch.empty(K, N, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_gemm(BF16, 0, _p(A), _p(W), _p(out), None, None, K, N, K, s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, W.float().t())
+
+
+def _attn_ref(q, k, v):
+    # q,k,v [H, L, 64] fp32 (q already scaled)
+    a = torch.softmax(q @ k.transpose(-1, -2), -1)
+    return a @ v
+
+
+@pytest.mark.parametrize("H,nseq,L", [(16, 2, 1376), (16, 3, 1374), (2, 3, 27), (4, 1, 2752), (2, 1, 64), (2, 2, 100)])
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_attention(dev, H, nseq, L, dt):
+    g = torch.Generator().manual_seed(H * 1000 + L)
+    M = nseq * L
+    q = _t16(torch.randn(H, M, 64, generator=g) * 0.125 * 1.5, dt).to(dev)
+    k = _t16(torch.randn(H, M, 64, generator=g) * 1.5, dt).to(dev)
+    v = _t16(torch.randn(H, M, 64, generator=g), dt).to(dev)
+    o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_attention(dt, _p(q), _p(k), _p(v), _p(o), H, M, L, 1, 0, s) == 0
+    torch.cuda.synchronize()
+    got = _from16(o, dt).reshape(M, H, 64)
+    ref = torch.empty(M, H, 64, device=dev)
+    for i in range(nseq):
+        sl = slice(i * L, (i + 1) * L)
+        ref[sl] = _attn_ref(q[:, sl].float(), k[:, sl].float(), v[:, sl].float()).transpose(0, 1)
+    e = _rel(got, ref)
+    print(f"attention H{H} nseq{nseq} L{L} dt{dt}: {e:.2e}")
+    # P is rounded to 16 bit before P@V and O is stored in 16 bit
+    assert e < (8e-3 if dt == BF16 else 1.5e-3)
+
+
+def test_attention_spike_forces_rescale(dev):
+    """Online-softmax rescale branch: one key far above the rest, placed in a late tile (guides rule 26)."""
+    H, L = 2, 640
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(H, L, 64, generator=g) * 0.125
+    k = torch.randn(H, L, 64, generator=g)
+    v = torch.randn(H, L, 64, generator=g)
+    k[:, 500] = q[:, 17] * 8 * 40.0  # row 17's score with key 500 is huge
+    q, k, v = [_t16(x, BF16).to(dev) for x in (q, k, v)]
+    o = torch.empty(L, H * 64, device=dev, dtype=torch.int16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_attention(BF16, _p(q), _p(k), _p(v), _p(o), H, L, L, 1, 0, s) == 0
+    torch.cuda.synchronize()
+    got = _from16(o, BF16).reshape(L, H, 64)
+    ref = _attn_ref(q.float(), k.float(), v.float()).transpose(0, 1)
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) < 8e-3
+
+
+def test_attention_kv_chunks_equals_concat(dev):
+    """Sharded global attention: keys/values given as 2 gathered chunks == one concatenated sequence."""
+    H, Lq, Lc = 4, 300, 300
+    g = torch.Generator().manual_seed(9)
+    q = _t16(torch.randn(H, Lq, 64, generator=g) * 0.125, BF16).to(dev)
+    kc = _t16(torch.randn(2, H, Lc, 64, generator=g), BF16).to(dev)
+    vc = _t16(torch.randn(2, H, Lc, 64, generator=g), BF16).to(dev)
+    o = torch.empty(Lq, H * 64, device=dev, dtype=torch.int16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_attention(BF16, _p(q), _p(kc), _p(vc), _p(o), H, Lq, Lq, 2, Lc, s) == 0
+    torch.cuda.synchronize()
+    kk = torch.cat([kc[0], kc[1]], 1).float()
+    vv = torch.cat([vc[0], vc[1]], 1).float()
+    ref = _attn_ref(q.float(), kk, vv).transpose(0, 1)
+    assert _rel(_from16(o, BF16).reshape(Lq, H, 64), ref) < 8e-3
+
+
+@pytest.mark.parametrize("D", [128, 256, 1024, 2048])
+def test_layernorm(dev, D):
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(333, D, generator=g) * 3 + 1).to(dev)
+    w = torch.randn(D, generator=g).to(dev)
+    b = torch.randn(D, generator=g).to(dev)
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty_like(x)
+    assert _lib().wm_op_layernorm(_p(x), _p(out), _p(w), _p(b), 333, D, 1e-5, 1, 0, s) == 0
+    o16 = torch.empty(333, D, device=dev, dtype=torch.int16)
+    assert _lib().wm_op_layernorm(_p(x), _p(o16), _p(w), _p(b), 333, D, 1e-5, 0, BF16, s) == 0
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 2e-6
+    assert _rel(_from16(o16, BF16), ref) < 4e-3
+
+
+def test_qkv_post_matches_oracle(dev):
+    """per-head LayerNorm(64) + 2-D RoPE + head-major relayout vs the oracle's rope_2d/layer_norm."""
+    from oracle import worldmirror_ref as R
+    H, S, gh, gw, psi = 4, 2, 4, 5, 7
+    P = psi + gh * gw
+    M, D = S * P, H * 64
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(M, 3 * D, generator=g)
+    nw = [torch.randn(64, generator=g) for _ in range(4)]
+    cos_t, sin_t = R.rope_tables(max(gh, gw) + 1, 32, 100.0)
+    cos16, sin16 = cos_t[:, :16].contiguous(), sin_t[:, :16].contiguous()
+    yy, xx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos = torch.cat([torch.zeros(psi, 2, dtype=torch.long), torch.stack([yy.flatten(), xx.flatten()], -1) + 1], 0)
+    pos = pos[None].expand(S, -1, -1).reshape(1, M, 2)
+    t = qkv.reshape(1, M, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q = R.rope_2d(R.layer_norm(t[0], nw[0], nw[1], 1e-5), pos, 100.0) * 0.125
+    k = R.rope_2d(R.layer_norm(t[1], nw[2], nw[3], 1e-5), pos, 100.0)
+    v = t[2]
+    d = [x.to(dev) for x in (qkv, *nw, cos16, sin16)]
+    outs = [torch.empty(H, M, 64, device=dev, dtype=torch.int16) for _ in range(3)]
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_qkv_post(F16, _p(d[0]), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]),
+                                 _p(d[5]), _p(d[6]), M, H, P, psi, gw, 0.125, s) == 0
+    torch.cuda.synchronize()
+    for got, ref, nm in zip(outs, (q, k, v), "qkv"):
+        e = _rel(_from16(got, F16).cpu(), ref[0])
+        print("qkv_post", nm, e)
+        assert e < 6e-4, nm
+
+
+def _conv_ref(x, w, b, stride, pad, relu_in, resid, resid_relu, resid2, dt):
+    xin = torch.relu(x) if relu_in else x
+    xin = _t16(xin, dt).float()
+    y = torch.nn.functional.conv2d(xin.permute(0, 3, 1, 2), w, b, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if resid is not None:
+        y = y + (torch.relu(resid) if resid_relu else resid)
+    if resid2 is not None:
+        y = y + resid2
+    return y
+
+
+@pytest.mark.parametrize("Cin,Cout,ks,stride,Hh,Ww", [(64, 64, 3, 1, 20, 16), (256, 256, 3, 1, 37, 37), (32, 32, 3, 1, 70, 56),
+                                                      (128, 32, 3, 1, 30, 30), (256, 256, 3, 2, 37, 37), (64, 64, 1, 1, 10, 8),
+                                                      (512, 256, 3, 1, 10, 10), (256, 128, 3, 1, 40, 40)])
+def test_conv(dev, Cin, Cout, ks, stride, Hh, Ww):
+    dt = F16
+    pad = 1 if ks == 3 else 0
+    g = torch.Generator().manual_seed(Cin + Cout + ks)
+    N = 2
+    x = torch.randn(N, Hh, Ww, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks))
+    w = _t16(w, dt).float().to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    Ho, Wo = (Hh + 2 * pad - ks) // stride + 1, (Ww + 2 * pad - ks) // stride + 1
+    resid = torch.randn(N, Ho, Wo, Cout, generator=g).to(dev)
+    resid2 = torch.randn(N, Ho, Wo, Cout, generator=g).to(dev)
+    w16 = _t16(w.permute(0, 2, 3, 1).contiguous(), dt)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for relu_in, use_res in ((0, False), (1, True)):
+        y = torch.empty(N, Ho, Wo, Cout, device=dev)
+        st = _lib().wm_op_conv(dt, _p(x), _p(w16), _p(b), _p(resid) if use_res else None, _p(resid2) if use_res else None, _p(y),
+                               N, Hh, Ww, Cin, Cout, ks, stride, pad, relu_in, 1 if use_res else 0, s)
+        assert st == 0
+        torch.cuda.synchronize()
+        ref = _conv_ref(x, w, b, stride, pad, relu_in, resid if use_res else None, True, resid2 if use_res else None, dt)
+        e = _rel(y, ref)
+        print(f"conv {Cin}->{Cout} k{ks}s{stride} relu{relu_in}: {e:.2e}")
+        assert e < 2e-5
+
+
+def test_bilinear(dev):
+    x = torch.randn(2, 19, 19, 64).to(dev)
+    for (Ho, Wo) in ((37, 37), (40, 31), (38, 38)):
+        y = torch.empty(2, Ho, Wo, 64, device=dev)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert _lib().wm_op_bilinear(_p(x), _p(y), 2, 19, 19, Ho, Wo, 64, s) == 0
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+        assert _rel(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,ldx", [(3, 256, 9, 12), (12, 512, 256, 256), (64, 6144, 2048, 2048), (5, 9, 1024, 1024)])
+def test_linear_f32(dev, M, N, K, ldx):
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.zeros(M, ldx)
+    X[:, :K] = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    Xd, Wd, bd = X.to(dev), W.to(dev), b.to(dev)
+    Y = torch.empty(M, N, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_linear_f32(_p(Xd), _p(Wd), _p(bd), _p(Y), M, N, K, ldx, 1, 2, s) == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.gelu(torch.nn.functional.silu(X[:, :K]) @ W.t() + b)
+    assert _rel(Y.cpu(), ref) < 5e-6
