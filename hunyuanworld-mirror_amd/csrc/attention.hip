@@ -27,6 +27,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
 
+// Combine a value with the one held by lane ^ 32.  v_permlane32_swap exchanges lanes 32-63 of its
+// first operand with lanes 0-31 of its second; written as inline asm on two distinct registers
+// because hipcc folds the builtin's two results when both inputs are the same SSA value.
+// The s_nop covers the VALU-write -> permlane read hazard (guides T21).
+__device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xhalf_max(float x) { float a, b; xhalf_pair(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xhalf_sum(float x) { float a, b; xhalf_pair(x, a, b); return a + b; }
+
 __device__ __forceinline__ uint32_t pack2(float a, float b, int T) {
   return T == WM_T_BF16 ? ((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16)) : ((uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16));
 }
@@ -150,11 +161,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
     for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);
-    {
-      const uint32_t mb = __builtin_bit_cast(uint32_t, mloc);
-      auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-      mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-    }
+    mloc = xhalf_max(mloc);
     if (!__all(mloc <= m_run)) {  // wave-uniform: rescale only when some row's max grew
       const float m_new = fmaxf(m_run, mloc);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
@@ -208,10 +215,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
 
   // ---- epilogue: O[q][head*64 + d] = O^T / l
   {
-    const uint32_t lb = __builtin_bit_cast(uint32_t, l_run);
-    auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
-    const float l = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / xhalf_sum(l_run);
     if (q_valid) {
       u16* op = (u16*)p.O + ((size_t)(seq_row0 + qrow_l) * p.H + head) * 64;
 #pragma unroll
