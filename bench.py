@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Headline benchmark: views/sec of the WorldMirror forward pass on MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (synthetic, random-init weights of the full 1.23 B-parameter architecture):
+  N = 1 : BASELINE config C2 — 8 views x 518 x 518, bf16, no priors, camera + depth + point + normal heads.
+  N > 1 : 8 views per GPU, view-sharded, K/V of every global-attention layer all-gathered over RCCL
+          (N = 8 is BASELINE config C4: 64 views) -> "scaling": "weak" (views per GPU fixed).
+A step = one full forward of the whole job; value = total views / step time (inputs resident in HBM).
+The JSON line also carries `roofline` (dominant kernel class, HIP-event timed on the launch stream) and,
+at N = 1, `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA, guides/MI355X_MICROARCH.md "Chip-level parameters"
+KINDS = {0: "global_attention", 1: "frame_dino_attention", 2: "gemm", 3: "dpt_conv"}
+
+
+def flop_model(cfg, n_local, n_total, H, W, heads=3):
+    """Algorithmic FLOPs per rank (2*MAC), per kernel class — BASELINE.md §3 formulas."""
+    ps, D = cfg.patch_size, cfg.embed_dim
+    hw = (H // ps) * (W // ps)
+    Td, P = 1 + cfg.num_register_tokens + hw, cfg.patch_start_idx + hw
+    lin_tok = 2 * D * (3 * D + D + 2 * cfg.mlp_ratio * D)
+    gemm = (cfg.dino_depth * n_local * Td + 2 * cfg.depth * n_local * P) * lin_tok
+    gemm += 2 * n_local * hw * (3 * ps * ps) * D
+    attn_local = cfg.dino_depth * n_local * 4 * Td * Td * D + cfg.depth * n_local * 4 * P * P * D
+    attn_global = cfg.depth * 4 * (n_local * P) * (n_total * P) * D
+    # DPT head: per view, scaled from the 518-px figure of BASELINE.md (298.6 GF) by pixel count
+    dpt = heads * 298.6e9 * (H * W) / (518.0 * 518.0) * n_local if D == 1024 else 0.0
+    return {"gemm": gemm, "frame_dino_attention": attn_local, "global_attention": attn_global, "dpt_conv": dpt,
+            "total": gemm + attn_local + attn_global + dpt + 1.6e9 * n_total}
+
+
+def cpu_baseline(cfg, H, W, budget_views=1):
+    """CPU oracle (oracle/worldmirror_ref.py, a port of the reference's fp32 path) on the host cores,
+    on a bounded sample of the same workload: `budget_views` views at the same resolution."""
+    from hunyuanworld_mirror_amd.weights import iter_params
+    from oracle import worldmirror_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = {k: torch.from_numpy(v) for k, v in iter_params(cfg)}
+    g = torch.Generator().manual_seed(1234)
+    img = torch.rand(1, budget_views, 3, H, W, generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        R.forward(P, {"img": img}, (0, 0, 0), cfg)
+    dt = time.time() - t0
+    del P
+    return {"value": budget_views / dt, "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"{budget_views} view(s) x {H}x{W}, full architecture, fp32 torch-CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views-per-gpu", type=int, default=8)
+    ap.add_argument("--size", type=int, default=518)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="scaled-down architecture (plumbing check only)")
+    a = ap.parse_args()
+
+    from hunyuanworld_mirror_amd import WorldMirror, WMConfig
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = WMConfig.tiny() if a.tiny else WMConfig()
+    H = W = a.size if not a.tiny else 70
+    n_local, n_total = a.views_per_gpu, a.views_per_gpu * world
+    m = WorldMirror(arch=cfg, dtype=a.dtype).init_synthetic_weights().to(dev)
+    if world > 1:
+        m.shard()
+    g = torch.Generator().manual_seed(1234)
+    views = {"img": torch.rand(1, n_total, 3, H, W, generator=g).to(dev)}
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        m(views)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m(views)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / a.steps * 1e3
+
+    # per-kernel-class timing: HIP events recorded by the library on the launch stream (one extra step)
+    m.profile(True)
+    m(views)
+    torch.cuda.synchronize(dev)
+    fl = flop_model(cfg, n_local, n_total, H, W)
+    classes = {}
+    for k, name in KINDS.items():
+        ms, n = m.profile_read(k)
+        if n:
+            classes[name] = {"ms_total": round(ms, 3), "launches": n, "avg_ms": round(ms / n, 4),
+                             "tflops": round(fl[name] / (ms * 1e-3) / 1e12, 1) if ms > 0 else None}
+    whole_ms, _ = m.profile_read(4)
+    m.profile(False)
+
+    if rank == 0:
+        dom = max(classes, key=lambda k: classes[k]["ms_total"])
+        ach = classes[dom]["tflops"]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": classes[dom]["avg_ms"], "flops_per_launch": fl[dom] / classes[dom]["launches"],
+                "classes": classes, "forward_ms_events": round(whole_ms, 3),
+                "whole_forward_tflops": round(fl["total"] / (ms_step * 1e-3) / 1e12, 1),
+                "whole_forward_frac": round(fl["total"] / (ms_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}
+        line = {"metric": "views/sec", "value": round(n_total / (ms_step * 1e-3), 3), "unit": "views/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                "config": {"workload": f"{n_total}-view {H}x{W} {a.dtype}, no priors, camera+depth+pointmap+normal heads, "
+                                       f"{n_local} views/GPU" + (", tiny arch" if a.tiny else ", full 1.23B-param arch"),
+                           "views_per_gpu": n_local, "global_views": n_total, "parallelism": f"view-shard x{world}"},
+                "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, H, W, 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

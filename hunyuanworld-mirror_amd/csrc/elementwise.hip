@@ -72,11 +72,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const WmLnArgs p) {
 template <int T>
 __global__ __launch_bounds__(256) void qkv_post_kernel(const WmQkvArgs p) {
   const int lane = threadIdx.x & 63, sub = lane & 15, hg = lane >> 4;
-  const int hgroups = p.H >> 2;
+  const int hgroups = (p.H + 3) >> 2;
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= (long long)p.M * hgroups) return;
   const int m = (int)(wid / hgroups);
-  const int head = ((int)(wid - (long long)m * hgroups) << 2) + hg;
+  const int head_raw = ((int)(wid - (long long)m * hgroups) << 2) + hg;
+  const bool head_ok = head_raw < p.H;            // H not a multiple of 4: surplus lanes compute on a
+  const int head = head_ok ? head_raw : p.H - 1;  // clamped head (shuffles stay in-group) and skip the store
   const int D = p.H * 64;
   const float* row = p.qkv + (size_t)m * 3 * D + head * 64 + sub * 4;
 
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const WmQkvArgs p) {
     u.x = (uint32_t)f2t<T>(v[0]) | ((uint32_t)f2t<T>(v[1]) << 16);
     u.y = (uint32_t)f2t<T>(v[2]) | ((uint32_t)f2t<T>(v[3]) << 16);
     u16* dst = (u16*)(which == 0 ? p.q : which == 1 ? p.k : p.v);
-    *(uint2*)(dst + obase) = u;
+    if (head_ok) *(uint2*)(dst + obase) = u;
   }
 }
 
@@ -310,8 +312,7 @@ hipError_t wm_launch_layernorm(const WmLnArgs& a, hipStream_t s) {
 
 hipError_t wm_launch_qkv_post(const WmQkvArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (a.H % 4) return hipErrorInvalidValue;
-  const long long waves = (long long)a.M * (a.H / 4);
+  const long long waves = (long long)a.M * ((a.H + 3) / 4);
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   if (a.dtype == WM_T_BF16) hipLaunchKernelGGL(qkv_post_kernel<WM_T_BF16>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(qkv_post_kernel<WM_T_F16>, grid, block, 0, s, a);

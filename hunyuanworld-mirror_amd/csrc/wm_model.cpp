@@ -418,7 +418,6 @@ extern "C" wm_status wm_create(const wm_config* cfg, int device, wm_handle** out
   *out = h;
   if (cfg->embed_dim / cfg->num_heads != 64 || cfg->embed_dim / cfg->dino_heads != 64)
     return fail(h, WM_ERR_INVALID, "backbone head_dim must be 64 (reference: 1024/16)");
-  if (cfg->num_heads % 4 && cfg->num_heads != 2) return fail(h, WM_ERR_INVALID, "num_heads must be 2 or a multiple of 4");
   if (cfg->embed_dim % 64) return fail(h, WM_ERR_INVALID, "embed_dim must be a multiple of 64");
   if (hipSetDevice(device) != hipSuccess) return fail(h, WM_ERR_HIP, "hipSetDevice failed");
   return WM_OK;
