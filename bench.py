@@ -45,14 +45,30 @@ def flop_model(cfg, n_local, n_total, H, W, heads=3):
             "total": gemm + attn_local + attn_global + dpt + 1.6e9 * n_total}
 
 
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share actually usable: affinity mask, capped at the GPU box's per-GPU share (16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("WM_BENCH_CORES", "16"))))
+
+
 def cpu_baseline(cfg, H, W, budget_views=1):
     """CPU oracle (oracle/worldmirror_ref.py, a port of the reference's fp32 path) on the host cores,
     on a bounded sample of the same workload: `budget_views` views at the same resolution."""
     from hunyuanworld_mirror_amd.weights import iter_params
     from oracle import worldmirror_ref as R
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: generating weights, {cores} threads")
     P = {k: torch.from_numpy(v) for k, v in iter_params(cfg)}
+    log("cpu_baseline: running the oracle")
     g = torch.Generator().manual_seed(1234)
     img = torch.rand(1, budget_views, 3, H, W, generator=g)
     t0 = time.time()
@@ -92,7 +108,10 @@ def main():
     cfg = WMConfig.tiny() if a.tiny else WMConfig()
     H = W = a.size if not a.tiny else 70
     n_local, n_total = a.views_per_gpu, a.views_per_gpu * world
-    m = WorldMirror(arch=cfg, dtype=a.dtype).init_synthetic_weights().to(dev)
+    torch.set_num_threads(host_cores())
+    log("generating + uploading weights")
+    m = WorldMirror(arch=cfg, dtype=a.dtype).to(dev).init_synthetic_weights()
+    log("weights ready")
     if world > 1:
         m.shard()
     g = torch.Generator().manual_seed(1234)
@@ -104,8 +123,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         m(views)
+        torch.cuda.synchronize(dev)
+        log(f"warmup {i} done")
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -117,6 +138,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_step = dt / a.steps * 1e3
+    log(f"timed region done: {ms_step:.2f} ms/step")
 
     # per-kernel-class timing: HIP events recorded by the library on the launch stream (one extra step)
     m.profile(True)

@@ -204,7 +204,8 @@ class WorldMirror:
         if st != 0:
             raise RuntimeError(f"wm_create: {self._err()}")
         self._device = torch.device("cuda", idx)
-        self._upload()
+        if self._host_weights:
+            self._upload()
         return self
 
     def cuda(self, device=None):
