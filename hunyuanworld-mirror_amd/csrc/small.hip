@@ -80,6 +80,62 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     }
 }
 
+// Weight-streaming form for M <= 32 rows (the camera head: M = number of views).  A block owns NC output
+// columns; its 4 waves split K in 1-KiB (256-float) slices so every W load is a fully coalesced
+// 16 B/lane wave-instruction and W is read exactly once; X (tiny) is re-read from L1/L2.
+template <int MT, int NC>
+__global__ __launch_bounds__(256) void linear_f32_stream_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                                const float* __restrict__ b, float* __restrict__ Y, int M,
+                                                                int N, int K, int ldx, int ldy, int pre_act, int post_act,
+                                                                const float* __restrict__ gamma, int accumulate) {
+  __shared__ float red[4][MT * NC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * NC, m0 = blockIdx.y * MT;
+  float acc[MT][NC];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[i][j] = 0.f;
+  for (int k0 = wave * 256; k0 < K; k0 += 1024) {
+    const int k = k0 + lane * 4;
+    if (k < K) {
+      float4 w[NC];
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        w[j] = n0 + j < N ? *(const float4*)(W + (size_t)(n0 + j) * K + k) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (m0 + i < M) {
+          float4 x = *(const float4*)(X + (size_t)(m0 + i) * ldx + k);
+          if (pre_act == 1) { x.x = silu(x.x); x.y = silu(x.y); x.z = silu(x.z); x.w = silu(x.w); }
+#pragma unroll
+          for (int j = 0; j < NC; ++j) acc[i][j] += x.x * w[j].x + x.y * w[j].y + x.z * w[j].z + x.w * w[j].w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const float v = wave_sum(acc[i][j]);
+      if (lane == 0) red[wave][i * NC + j] = v;
+    }
+  __syncthreads();
+  if (tid < MT * NC) {
+    const int i = tid / NC, j = tid - i * NC;
+    const int m = m0 + i, n = n0 + j;
+    if (m < M && n < N) {
+      float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + (b ? b[n] : 0.f);
+      if (post_act == 1) v = silu(v);
+      else if (post_act == 2) v = gelu_erf(v);
+      if (gamma) v *= gamma[n];
+      float* y = Y + (size_t)m * ldy + n;
+      *y = accumulate ? *y + v : v;
+    }
+  }
+}
+
 // softmax(q k^T / sqrt(hd)) v over S tokens; one wave per (head, query)
 __global__ __launch_bounds__(64) void small_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S,
                                                              int heads, int hd) {
@@ -177,6 +233,16 @@ hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, 
                                 int ldy, int pre_act, int post_act, const float* gamma, int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0) return hipSuccess;
   if (ldx % 4) return hipErrorInvalidValue;
+  if (K % 4 == 0 && K >= 256) {  // weight-streaming path
+#define WM_STREAM(MT)                                                                                              \
+  hipLaunchKernelGGL((linear_f32_stream_kernel<MT, 4>), dim3((N + 3) / 4, (M + MT - 1) / MT), dim3(256), 0, s, X, W, b, Y, \
+                     M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate)
+    if (M <= 8) WM_STREAM(8);
+    else if (M <= 16) WM_STREAM(16);
+    else WM_STREAM(32);
+#undef WM_STREAM
+    return hipGetLastError();
+  }
   dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM), block(256);
   hipLaunchKernelGGL(linear_f32_kernel, grid, block, 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
   return hipGetLastError();

@@ -75,8 +75,10 @@ def rope_2d(x: Tensor, pos: Tensor, base: float) -> Tensor:
 
 
 def attention(x: Tensor, P, p: str, heads: int, pos: Optional[Tensor], qk_norm: bool,
-              rope_base: float) -> Tensor:
-    """src/models/layers/attention.py:48-69 (softmax(q k^T / sqrt(hd)) v, no mask)."""
+              rope_base: float, kv_gather=None) -> Tensor:
+    """src/models/layers/attention.py:48-69 (softmax(q k^T / sqrt(hd)) v, no mask).
+    kv_gather (view-sharded evaluation): maps this rank's K or V [B,H,L,hd] to the
+    keys/values of ALL ranks concatenated on L; queries stay local."""
     B, L, C = x.shape
     hd = C // heads
     qkv = linear(x, P, p + "qkv").reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
@@ -87,6 +89,8 @@ def attention(x: Tensor, P, p: str, heads: int, pos: Optional[Tensor], qk_norm: 
     if pos is not None:
         q = rope_2d(q, pos, rope_base)
         k = rope_2d(k, pos, rope_base)
+    if kv_gather is not None:
+        k, v = kv_gather(k), kv_gather(v)
     o = torch.empty_like(q)
     scale = hd ** -0.5
     step = 2048  # row blocks keep the score matrix small; result is identical
@@ -98,10 +102,10 @@ def attention(x: Tensor, P, p: str, heads: int, pos: Optional[Tensor], qk_norm: 
 
 
 def block(x: Tensor, P, p: str, heads: int, eps: float, pos=None, qk_norm=False,
-          rope_base: float = 100.0) -> Tensor:
+          rope_base: float = 100.0, kv_gather=None) -> Tensor:
     """src/models/layers/block.py:72-93 eval branch; LayerScale layer_scale.py:16-17."""
     h = layer_norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], eps)
-    x = x + attention(h, P, p + "attn.", heads, pos, qk_norm, rope_base) * P[p + "ls1.gamma"]
+    x = x + attention(h, P, p + "attn.", heads, pos, qk_norm, rope_base, kv_gather) * P[p + "ls1.gamma"]
     h = layer_norm(x, P[p + "norm2.weight"], P[p + "norm2.bias"], eps)
     h = linear(gelu_erf(linear(h, P, p + "mlp.fc1")), P, p + "mlp.fc2")
     return x + h * P[p + "ls2.gamma"]
@@ -221,14 +225,17 @@ def extract_priors(views: Dict[str, Tensor]):
 # ----------------------------------------------------------------------------------------------
 # a3-a10: backbone
 # ----------------------------------------------------------------------------------------------
-def special_tokens(tok: Tensor, S: int) -> Tensor:
-    """visual_transformer.py:397-416: slot 0 -> view 0, slot 1 -> views 1.. ; [S,X,D] (B=1)."""
-    return torch.cat([tok[0, 0:1], tok[0, 1:2].expand(S - 1, -1, -1)], 0)
+def special_tokens(tok: Tensor, S: int, first_view: int = 0) -> Tensor:
+    """visual_transformer.py:397-416: slot 0 -> (global) view 0, slot 1 -> views 1.. ; [S,X,D] (B=1)."""
+    idx = [0 if first_view + i == 0 else 1 for i in range(S)]
+    return tok[0, idx]
 
 
 def backbone(P, img: Tensor, cfg, priors=None, cond_flags=(0, 0, 0),
-             collect: Optional[dict] = None) -> Tuple[List[Tensor], int]:
-    """visual_transformer.py:250-341. img [1,S,3,H,W] in [0,1] -> 4 x [1,S,P,2D]."""
+             collect: Optional[dict] = None, shard=None) -> Tuple[List[Tensor], int]:
+    """visual_transformer.py:250-341. img [1,S,3,H,W] in [0,1] -> 4 x [1,S,P,2D].
+    shard = (first_view, kv_gather): img/priors hold only this rank's views."""
+    first_view, kv_gather = shard if shard is not None else (0, None)
     v = "visual_geometry_transformer."
     B, S, C, H, W = img.shape
     assert B == 1
@@ -241,8 +248,8 @@ def backbone(P, img: Tensor, cfg, priors=None, cond_flags=(0, 0, 0),
     if collect is not None:
         collect["dino"] = patches
     D = patches.shape[-1]
-    cam = special_tokens(P[v + "cam_token"], S)
-    reg = special_tokens(P[v + "reg_token"], S)
+    cam = special_tokens(P[v + "cam_token"], S, first_view)
+    reg = special_tokens(P[v + "reg_token"], S, first_view)
     gh, gw = H // cfg.patch_size, W // cfg.patch_size
     if cfg.enable_cond:  # :343-371
         depths, rays, poses = priors if priors is not None else (None, None, None)
@@ -280,7 +287,7 @@ def backbone(P, img: Tensor, cfg, priors=None, cond_flags=(0, 0, 0),
                     pos_f, True, cfg.rope_freq)
         frame_out = tok
         tok = block(tok.reshape(1, S * Pn, D), P, v + f"global_blocks.{i}.", cfg.num_heads, 1e-5,
-                    pos_g, True, cfg.rope_freq)
+                    pos_g, True, cfg.rope_freq, kv_gather)
         if i in cfg.intermediate_idxs:
             taps.append(torch.cat([frame_out.reshape(1, S, Pn, D), tok.reshape(1, S, Pn, D)], -1))
     return taps, psi
@@ -289,10 +296,13 @@ def backbone(P, img: Tensor, cfg, priors=None, cond_flags=(0, 0, 0),
 # ----------------------------------------------------------------------------------------------
 # a11-a12: camera head
 # ----------------------------------------------------------------------------------------------
-def camera_head(P, taps: Sequence[Tensor], cfg) -> Tensor:
-    """src/models/heads/camera_head.py:58-104 -> last iterate [1,S,9]."""
+def camera_head(P, taps: Sequence[Tensor], cfg, tok_gather=None) -> Tensor:
+    """src/models/heads/camera_head.py:58-104 -> last iterate [1,S,9].
+    tok_gather (sharded evaluation): local camera tokens [1,S_local,2D] -> all views [1,S,2D]."""
     c = "cam_head."
     tok = layer_norm(taps[-1][:, :, 0], P[c + "token_norm.weight"], P[c + "token_norm.bias"], 1e-5)
+    if tok_gather is not None:
+        tok = tok_gather(tok)
     B, S, D2 = tok.shape
     pred = None
     for _ in range(cfg.cam_steps):
