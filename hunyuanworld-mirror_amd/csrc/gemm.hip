@@ -5,172 +5,287 @@
 //  heads/dense_head.py:53-68,204-208).  Both operands are K-contiguous ("NT"), which is what
 // torch's Linear weight layout gives for free and what the 32x32x16 MFMA fragments want.
 //
-// Tile: 128x128x64, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles.  Global->LDS staging
-// is direct LDS-DMA (global_load_lds, 16 B/lane); the XOR swizzle that makes the ds_read_b128
-// fragment reads conflict-free is applied to the per-lane SOURCE address (guides §5.4 rule 21).
+// Structure
+//  * tile (WM*TM*32) x (WN*TN*32) x 64, WM x WN waves, each wave TM x TN MFMA 32x32 tiles;
+//  * global -> LDS by LDS-DMA (global_load_lds, 16 B/lane, 1 KiB per wave-instruction); the XOR
+//    swizzle that makes the ds_read_b128 fragment reads conflict-free is applied to the per-lane
+//    SOURCE address (guides §5.4 rule 21);
+//  * NSTAGE-deep LDS ring, one raw s_barrier per K-tile, counted s_waitcnt vmcnt(N) so NSTAGE-2
+//    tiles stay in flight across the barrier (guides "Pipelining across barriers", T3+T4);
+//  * the MFMA is issued as D = W_frag * A_frag (operands swapped), so a lane owns one output ROW
+//    and 4 consecutive COLUMNS per register group: the epilogue reads/writes float4 (16 B/lane).
 #include "wm_common.h"
 #include "wm_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
-// stage one 128 x 64 (16-bit) operand tile: 16 wave-instructions of 1 KiB (8 rows x 128 B)
-__device__ __forceinline__ void stage_tile(const u16* __restrict__ g, int ld, int row0, int nrows, int k0,
-                                           char* lds_tile, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rg = (wave * 4 + i) * 8;       // first row of this 8-row group (wave-uniform)
-    const int r = rg + (lane >> 3);          // tile row this lane fetches
-    const int c = (lane & 7) ^ ((r >> 1) & 7);  // source chunk so that LDS[r][p] = G[r][p ^ swz(r)]
-    int gr = row0 + r;
-    gr = gr < nrows ? gr : nrows - 1;        // clamp: out-of-range rows are masked in the epilogue
-    const u16* src = g + (size_t)gr * ld + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(lds_tile + rg * 128), 16, 0, 0);
-  }
+// one 1-KiB LDS-DMA piece = 8 rows x 128 B of an operand tile
+__device__ __forceinline__ void stage_piece(const u16* __restrict__ g, int ld, int row0, int nrows, int k0, char* lds_tile,
+                                            int piece, int lane) {
+  const int r = piece * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ ((r >> 1) & 7);  // LDS[r][p] = G[r][p ^ swz(r)]
+  int gr = row0 + r;
+  gr = gr < nrows ? gr : nrows - 1;  // clamp: out-of-range rows are masked in the epilogue
+  __builtin_amdgcn_global_load_lds((glb_vp)(g + (size_t)gr * ld + k0 + c * 8), (lds_vp)(lds_tile + piece * 1024), 16, 0, 0);
 }
 
 __device__ __forceinline__ s16x8 lds_frag(const char* tile, int row, int chunk) {
   return *(const s16x8*)(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int T, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const WmGemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16K | B 16K]
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE, int ILV>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs p) {
+  constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 8, PB = BN / 8;       // 1-KiB pieces per operand tile
+  constexpr int PPW = (PA + PB) / NW;           // pieces per wave per K-tile
+  static_assert((PA + PB) % NW == 0, "pieces must divide over waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
   const u16* A = (const u16*)p.A;
   const u16* W = (const u16*)p.W;
 
-  f32x16 acc[2][2];
+  auto stage_part = [&](int kt, int s, int i0, int i1) {
+    char* base = smem + s * STAGE;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = i0; i < i1; ++i) {
+      const int pc = wave * PPW + i;  // wave-uniform
+      if (pc < PA) stage_piece(A, p.lda, m0, p.M, kt * BK, base, pc, lane);
+      else stage_piece(W, p.ldw, n0, p.N, kt * BK, base + A_BYTES, pc - PA, lane);
+    }
+  };
+  auto stage = [&](int kt, int s) { stage_part(kt, s, 0, PPW); };
+
+  f32x16 acc[TM][TN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  stage_tile(A, p.lda, m0, p.M, 0, smem, wave, lane);
-  stage_tile(W, p.ldw, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
-  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
-  int cur = 0;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+
   for (int t = 0; t < nk; ++t) {
-    const char* tA = smem + cur * 2 * TILE_BYTES;
-    const char* tB = tA + TILE_BYTES;
-    if (t + 1 < nk) {
-      char* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile(A, p.lda, m0, p.M, (t + 1) * BK, nA, wave, lane);
-      stage_tile(W, p.ldw, n0, p.N, (t + 1) * BK, nA + TILE_BYTES, wave, lane);
-    }
+    // tile t must have landed; tiles t+1 .. t+NSTAGE-2 may stay in flight
+    const int ahead = min(nk - 1 - t, NSTAGE - 2);
+    if (ahead >= 2) wait_vmcnt<2 * PPW>();
+    else if (ahead == 1) wait_vmcnt<PPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's pieces of tile t landed; everyone finished tile t-1
+    const bool more = t + NSTAGE - 1 < nk;
+    if (!ILV && more) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
+    const char* tA = smem + (t % NSTAGE) * STAGE;
+    const char* tB = tA + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (ILV && more) {  // spread the LDS-DMA issue over the four MFMA groups of this K-tile
+        constexpr int Q = (PPW + 3) / 4;
+        stage_part(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE, ks * Q < PPW ? ks * Q : PPW, (ks + 1) * Q < PPW ? (ks + 1) * Q : PPW);
+      }
       const int ch = 2 * ks + (lane >> 5);
-      s16x8 a[2], b[2];
+      s16x8 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = lds_frag(tA, wm * 64 + i * 32 + (lane & 31), ch);
+      for (int i = 0; i < TM; ++i) a[i] = lds_frag(tA, (wm * TM + i) * 32 + (lane & 31), ch);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = lds_frag(tB, wn * 64 + j * 32 + (lane & 31), ch);
+      for (int j = 0; j < TN; ++j) b[j] = lds_frag(tB, (wn * TN + j) * 32 + (lane & 31), ch);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32<T>(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(b[j], a[i], acc[i][j]);  // D[n][m]: lane = row m
+      if (ILV) __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    cur ^= 1;
   }
 
-  // ---------------- epilogue ----------------
+  // ---------------- epilogue: lane (m = lane&31, h = lane>>5), reg 4g+e <-> col 8g + 4h + e ----------------
+  const int h4 = (lane >> 5) * 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-    if (col >= p.N) continue;
-    const float bias = p.bias ? p.bias[col] : 0.f;
-    float gamma = 1.f;
-    if constexpr (EPI == WM_EPI_RESID) gamma = p.gamma[col];
+  for (int i = 0; i < TM; ++i) {
+    const int row = m0 + (wm * TM + i) * 32 + (lane & 31);
+    if (row >= p.M) continue;
+    size_t orow = (size_t)row;
+    int q = 0;
+    if constexpr (EPI == WM_EPI_ROWMAP_ADD) {
+      const int g = row / p.rows_per_group;
+      q = row - g * p.rows_per_group;
+      orow = (size_t)g * p.out_group + p.out_off + q;
+    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < TN; ++j) {
+      const int cb = n0 + (wn * TN + j) * 32 + h4;
+      if constexpr (EPI == WM_EPI_CONVT) {
+        // k==stride ConvTranspose2d as GEMM: col = (ii*k + jj)*Cout + co; row = (n*gh + y)*gw + x
+        const int hw = p.ct_gh * p.ct_gw;
+        const int n = row / hw, yx = row - n * hw, y = yx / p.ct_gw, x = yx - y * p.ct_gw;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] + bias;
-        if constexpr (EPI == WM_EPI_F32) {
-          ((float*)p.C)[(size_t)row * p.ldc + col] = v;
-        } else if constexpr (EPI == WM_EPI_T16) {
-          ((u16*)p.C)[(size_t)row * p.ldc + col] = f2t<T>(v);
-        } else if constexpr (EPI == WM_EPI_GELU_T16) {
-          ((u16*)p.C)[(size_t)row * p.ldc + col] = f2t<T>(gelu_erf(v));
-        } else if constexpr (EPI == WM_EPI_RESID) {
-          float* c = (float*)p.C + (size_t)row * p.ldc + col;
-          *c = *c + gamma * v;
-        } else if constexpr (EPI == WM_EPI_ROWMAP_ADD) {
-          // out[(row / rpg) * out_group + out_off + row % rpg][col] (+)= v + add[(row % rpg)][col]
-          const int g = row / p.rows_per_group, q = row - g * p.rows_per_group;
-          const size_t o = ((size_t)g * p.out_group + p.out_off + q) * p.ldc + col;
-          float x = v;
-          if (p.add) x += p.add[(size_t)q * p.N + col];
-          if (p.out16) {
-            ((u16*)p.C)[o] = f2t<T>(x);
-          } else {
-            float* c = (float*)p.C + o;
-            if (p.accumulate) x += *c;
-            *c = x;
-          }
-        } else if constexpr (EPI == WM_EPI_CONVT) {
-          // k==stride ConvTranspose2d as GEMM: col = (i*ks + j)*Cout + co; row = (n*gh + y)*gw + x
-          const int co = col % p.ct_cout, ij = col / p.ct_cout;
+        for (int g = 0; g < 4; ++g) {
+          const int col = cb + 8 * g;
+          if (col >= p.N) continue;
+          const int co = col % p.ct_cout, ij = col / p.ct_cout;  // 4 consecutive cols share (ii,jj): Cout % 4 == 0
           const int ii = ij / p.ct_k, jj = ij - ii * p.ct_k;
-          const int hw = p.ct_gh * p.ct_gw;
-          const int n = row / hw, yx = row - n * hw, y = yx / p.ct_gw, x = yx - y * p.ct_gw;
           const size_t o = (((size_t)n * p.ct_gh * p.ct_k + (y * p.ct_k + ii)) * (p.ct_gw * p.ct_k) + (x * p.ct_k + jj)) * p.ct_cout + co;
-          ((float*)p.C)[o] = acc[i][j][r] + p.bias[co];
+          const float4 bs = *(const float4*)(p.bias + co);
+          *(float4*)((float*)p.C + o) = make_float4(acc[i][j][4 * g] + bs.x, acc[i][j][4 * g + 1] + bs.y,
+                                                    acc[i][j][4 * g + 2] + bs.z, acc[i][j][4 * g + 3] + bs.w);
+        }
+      } else {
+        float4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = cb + 8 * g;
+          ok[g] = col < p.N;  // N % 4 == 0: a float4 is all-in or all-out
+          const int cc = ok[g] ? col : 0;
+          const float4 bs = p.bias ? *(const float4*)(p.bias + cc) : make_float4(0, 0, 0, 0);
+          v[g] = make_float4(acc[i][j][4 * g] + bs.x, acc[i][j][4 * g + 1] + bs.y, acc[i][j][4 * g + 2] + bs.z,
+                             acc[i][j][4 * g + 3] + bs.w);
+        }
+        if constexpr (EPI == WM_EPI_F32) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (ok[g]) *(float4*)((float*)p.C + orow * p.ldc + cb + 8 * g) = v[g];
+        } else if constexpr (EPI == WM_EPI_T16 || EPI == WM_EPI_GELU_T16) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (!ok[g]) continue;
+            float4 x = v[g];
+            if constexpr (EPI == WM_EPI_GELU_T16) x = make_float4(gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w));
+            uint2 u;
+            u.x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
+            u.y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
+            *(uint2*)((u16*)p.C + orow * p.ldc + cb + 8 * g) = u;
+          }
+        } else if constexpr (EPI == WM_EPI_RESID) {
+          float4 old[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) old[g] = ok[g] ? *(const float4*)((const float*)p.C + orow * p.ldc + cb + 8 * g) : make_float4(0, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (!ok[g]) continue;
+            const float4 gm = *(const float4*)(p.gamma + cb + 8 * g);
+            *(float4*)((float*)p.C + orow * p.ldc + cb + 8 * g) =
+                make_float4(old[g].x + gm.x * v[g].x, old[g].y + gm.y * v[g].y, old[g].z + gm.z * v[g].z, old[g].w + gm.w * v[g].w);
+          }
+        } else if constexpr (EPI == WM_EPI_ROWMAP_ADD) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (!ok[g]) continue;
+            const int col = cb + 8 * g;
+            float4 x = v[g];
+            if (p.add) {
+              const float4 ad = *(const float4*)(p.add + (size_t)q * p.N + col);
+              x.x += ad.x; x.y += ad.y; x.z += ad.z; x.w += ad.w;
+            }
+            const size_t o = orow * p.ldc + col;
+            if (p.out16) {
+              uint2 u;
+              u.x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
+              u.y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
+              *(uint2*)((u16*)p.C + o) = u;
+            } else {
+              float* c = (float*)p.C + o;
+              if (p.accumulate) {
+                const float4 od = *(const float4*)c;
+                x.x += od.x; x.y += od.y; x.z += od.z; x.w += od.w;
+              }
+              *(float4*)c = x;
+            }
+          }
         }
       }
     }
   }
 }
 
-template <int T>
-hipError_t launch_T(const WmGemmArgs& a, hipStream_t s) {
+template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE, int ILV>
+hipError_t launch_cfg(const WmGemmArgs& a, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t shm = (size_t)NSTAGE * (BM + BN) * BK * 2;
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
-  dim3 grid(ntm * ntn), block(256);
-  const size_t shm = 4 * TILE_BYTES;
-#define WM_LAUNCH(E)                                                                           \
-  case E: {                                                                                    \
-    static bool attr = false;                                                                  \
-    if (!attr) {                                                                               \
-      hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-      attr = true;                                                                             \
-    }                                                                                          \
-    hipLaunchKernelGGL((gemm_nt_kernel<T, E>), grid, block, shm, s, a);                         \
-    break;                                                                                     \
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, TN, NSTAGE, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr = true;
   }
-  switch (a.epi) {
-    WM_LAUNCH(WM_EPI_F32)
-    WM_LAUNCH(WM_EPI_T16)
-    WM_LAUNCH(WM_EPI_GELU_T16)
-    WM_LAUNCH(WM_EPI_RESID)
-    WM_LAUNCH(WM_EPI_ROWMAP_ADD)
-    WM_LAUNCH(WM_EPI_CONVT)
+  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, TN, NSTAGE, ILV>), dim3(ntm * ntn), dim3(WM * WN * 64), shm, s, a);
+  return hipGetLastError();
+}
+
+// tile configurations: id -> (WM, WN, TM, TN, NSTAGE)
+//  0: 128x128, 4 waves, 2-stage (64 KiB, 2 blocks/CU)     1: 256x128, 8 waves, 3-stage (144 KiB)
+//  2: 128x256, 8 waves, 3-stage (144 KiB)                 3: 128x128, 8 waves (32x64 per wave), 4-stage (128 KiB)
+//  4: 256x256, 8 waves (128x64 per wave), 2-stage (128 KiB)   5: 192x256, 8 waves (96x64 per wave), 2-stage (112 KiB)
+template <int T, int EPI>
+hipError_t launch_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
+  switch (cfg) {
+    case 0: return launch_cfg<T, EPI, 2, 2, 2, 2, 2, 0>(a, s);
+    case 1: return launch_cfg<T, EPI, 4, 2, 2, 2, 3, 0>(a, s);
+    case 2: return launch_cfg<T, EPI, 4, 2, 2, 2, 3, 1>(a, s);
+    case 3: return launch_cfg<T, EPI, 2, 4, 4, 2, 2, 1>(a, s);
+    case 4: return launch_cfg<T, EPI, 2, 4, 4, 2, 2, 0>(a, s);
+    case 5: return launch_cfg<T, EPI, 2, 4, 3, 2, 2, 0>(a, s);
     default: return hipErrorInvalidValue;
   }
-#undef WM_LAUNCH
-  return hipGetLastError();
+}
+
+template <int T>
+hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
+  switch (a.epi) {
+    case WM_EPI_F32: return launch_E<T, WM_EPI_F32>(a, cfg, s);
+    case WM_EPI_T16: return launch_E<T, WM_EPI_T16>(a, cfg, s);
+    case WM_EPI_GELU_T16: return launch_E<T, WM_EPI_GELU_T16>(a, cfg, s);
+    case WM_EPI_RESID: return launch_E<T, WM_EPI_RESID>(a, cfg, s);
+    case WM_EPI_ROWMAP_ADD: return launch_E<T, WM_EPI_ROWMAP_ADD>(a, cfg, s);
+    case WM_EPI_CONVT: return launch_E<T, WM_EPI_CONVT>(a, cfg, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+int pick_cfg(const WmGemmArgs& a) {
+  static const int forced = [] { const char* e = getenv("WM_GEMM_CFG"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced;
+  if (a.M <= 128 || a.N <= 128) return 0;
+  // minimise (rounds over the CUs) x (tile area / relative tile efficiency): tile quantisation is the
+  // first-order loss at M = 11008 (e.g. 516 tiles of 256^2 on 256 CUs = 3 rounds)
+  static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+  struct Cand { int id, bm, bn, per_cu; float eff; };
+  static const Cand cands[] = {{4, 256, 256, 1, 1.00f}, {5, 192, 256, 1, 0.93f}, {1, 256, 128, 1, 0.86f}, {0, 128, 128, 2, 0.72f}};
+  int best = 4;
+  float best_cost = 1e30f;
+  for (const Cand& c : cands) {
+    const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
+    const long rounds = (tiles + (long)ncu * c.per_cu - 1) / ((long)ncu * c.per_cu);
+    const float cost = (float)rounds * c.per_cu * c.bm * c.bn / c.eff;  // co-resident blocks share the CU
+    if (cost < best_cost) { best_cost = cost; best = c.id; }
+  }
+  return best;
 }
 
 }  // namespace
 
 hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (a.K <= 0 || a.K % BK != 0) return hipErrorInvalidValue;
+  if (a.K <= 0 || a.K % BK != 0 || a.N % 4 != 0) return hipErrorInvalidValue;
   if ((a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;  // 16-B aligned rows
-  return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, s) : launch_T<WM_T_F16>(a, s);
+  if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
+  if (a.epi != WM_EPI_CONVT && (a.ldc & 3)) return hipErrorInvalidValue;
+  const int cfg = pick_cfg(a);
+  return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, cfg, s) : launch_T<WM_T_F16>(a, cfg, s);
 }
