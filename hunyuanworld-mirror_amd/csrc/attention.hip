@@ -19,6 +19,8 @@
 #include "wm_common.h"
 #include "wm_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int KVB = 64;                 // keys per tile
@@ -38,15 +40,35 @@ __device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
 __device__ __forceinline__ float xhalf_max(float x) { float a, b; xhalf_pair(x, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float xhalf_sum(float x) { float a, b; xhalf_pair(x, a, b); return a + b; }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+// two fp32 -> one packed 16-bit pair: a single v_cvt_pk_{bf16,f16}_f32
 __device__ __forceinline__ uint32_t pack2(float a, float b, int T) {
-  return T == WM_T_BF16 ? ((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16)) : ((uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16));
+  const f32x2 v = {a, b};
+  return T == WM_T_BF16 ? __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2))
+                        : __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 
-template <int T, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
+// smallest T-representable value >= x (x finite): used for the running max so that the value the MFMA
+// subtracts (carried as a 16-bit operand) is exactly m_run and scores never exceed it
+template <int T>
+__device__ __forceinline__ float ceil_t16(float x) {
+  u16 u = f2t<T>(x);
+  float y = t2f<T>(u);
+  if (y < x) {
+    if (u == 0x8000) u = 0;
+    u = (u & 0x8000) ? (u16)(u - 1) : (u16)(u + 1);
+    y = t2f<T>(u);
+  }
+  return y;
+}
+
+template <int T, int NW, int QB, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArgs p) {
   constexpr int NT = NW * 64;
-  constexpr int QT = NW * 32;
-  constexpr int CPT = 512 / NT;  // 16-B chunks per thread per tile (K and V each)
+  constexpr int QT = NW * 32 * QB;  // query rows per block; each wave owns QB blocks of 32 rows
+  constexpr int CPT = 512 / NT;     // 16-B chunks per thread per tile (K and V each)
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K|V]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,13 +85,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (q=ql, h) holds Q[q][16ks + 8h + j]
   const u16* Qh = (const u16*)p.Q + (size_t)head * p.q_head_stride * 64;
-  int qrow_l = qt * QT + wave * 32 + ql;              // row within the sequence
-  const bool q_valid = qrow_l < p.seq_len;
-  qrow_l = q_valid ? qrow_l : p.seq_len - 1;
-  const u16* qptr = Qh + (size_t)(seq_row0 + qrow_l) * 64;
-  s16x8 qf[4];
+  int qrow[QB];
+  bool q_valid[QB];
+  s16x8 qf[QB][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const s16x8*)(qptr + ks * 16 + h * 8);
+  for (int b = 0; b < QB; ++b) {
+    int r = qt * QT + (wave * QB + b) * 32 + ql;  // row within the sequence
+    q_valid[b] = r < p.seq_len;
+    r = q_valid[b] ? r : p.seq_len - 1;
+    qrow[b] = r;
+    const u16* qptr = Qh + (size_t)(seq_row0 + r) * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const s16x8*)(qptr + ks * 16 + h * 8);
+  }
 
   // ---- K/V segments
   const int seg_rows = p.kv_chunks > 1 ? p.kv_rows_per_chunk : p.seq_len;
@@ -108,12 +136,28 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
     }
   };
 
-  f32x16 ot[2];
+  // Scores arrive in log2 units (q is pre-scaled by log2(e)/sqrt(d)).  The running max is subtracted
+  // INSIDE the MFMA: one extra k-step multiplies a constant K-side fragment (1.0 at k=0) with a Q-side
+  // fragment holding -m_run at k=0, so S' = S - m_run comes out of the matrix pipe and the softmax
+  // needs no per-score FMA (the VALU, not the MFMA, bounds this kernel at head_dim 64).
+  f32x16 ot[QB][2];
+  float m_run[QB], l_run[QB];
+  s16x8 qx[QB];
+  s16x8 kx;
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int j = 0; j < 8; ++j) kx[j] = 0;
+  if (h == 0) kx[0] = (short)f2t<T>(1.0f);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int b = 0; b < QB; ++b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qx[b][j] = 0;
+    m_run[b] = 0.f;
+    l_run[b] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[b][d][r] = 0.f;
+  }
 
   load_tile(0);
   store_tile(0);
@@ -128,17 +172,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
     const char* vt = kt + TILE_B;
     if (t + 1 < ntiles) load_tile(t + 1);  // global -> regs, hidden under the MFMA phase
 
-    // ---- S^T = K Q^T : st[kt][r] = S[key = 32kt + (r&3)+8(r>>2)+4h][q = ql]
-    f32x16 st[2];
+    // ---- S^T = K Q^T : st[b][k2][r] = S[key = 32k2 + (r&3)+8(r>>2)+4h][q = ql of block b]
+    f32x16 st[QB][2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[k2][r] = 0.f;
       const int key = k2 * 32 + ql;
+      const f32x16 zero = {0};
+#pragma unroll
+      for (int b = 0; b < QB; ++b) st[b][k2] = mfma32<T>(kx, qx[b], zero);  // -m_run broadcast to every key row
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const s16x8 kf = *(const s16x8*)(kt + key * 128 + (((2 * ks + h) ^ ((key >> 1) & 7)) << 4));
-        st[k2] = mfma32<T>(kf, qf[ks], st[k2]);
+#pragma unroll
+        for (int b = 0; b < QB; ++b) st[b][k2] = mfma32<T>(kf, qf[b][ks], st[b][k2]);
       }
     }
     // ---- tail mask (wave-uniform branch; only the last tile of a segment)
@@ -147,49 +193,62 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
       const int valid = seg_rows - j * KVB;
       if (valid < KVB) {
 #pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = k2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              if (key >= valid) st[b][k2][r] = -INFINITY;
+            }
+      }
+    }
+    // ---- online softmax in base 2 (q was pre-scaled by log2(e)/sqrt(d))
+    s16x8 pf[QB][2][2];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float mloc = st[b][0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[b][0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[b][1][r]);
+      mloc = xhalf_max(mloc);  // max of S' = S - m_run over this tile (same value in both lane halves)
+      if (t == 0 || !__all(mloc <= 0.f)) {  // wave-uniform: some row's max grew (always on the first tile)
+        const float cand = m_run[b] + (t == 0 ? mloc : fmaxf(mloc, 0.f));
+        const float m_new = ceil_t16<T>(cand);
+        const float d2 = m_new - m_run[b];
+        m_run[b] = m_new;
+#pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = k2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (key >= valid) st[k2][r] = -INFINITY;
-          }
-      }
-    }
-    // ---- online softmax (scores already carry 1/sqrt(d): q was pre-scaled)
-    float mloc = st[0][0];
+          for (int r = 0; r < 16; ++r) st[b][k2][r] -= d2;
+        if (t > 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d2);
+          l_run[b] *= alpha;
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);
+          for (int d = 0; d < 2; ++d)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);
-    mloc = xhalf_max(mloc);
-    if (!__all(mloc <= m_run)) {  // wave-uniform: rescale only when some row's max grew
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
-    }
-    const float mc = -m_run * LOG2E;
-    s16x8 pf[2][2];
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      float pv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[k2][r], LOG2E, mc));
-        l_run += pv[r];
+            for (int r = 0; r < 16; ++r) ot[b][d][r] *= alpha;
+        }
+        if (h == 0) qx[b][0] = (short)f2t<T>(-m_new);  // exact: m_new is T-representable
       }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        uint4 u;
-        u.x = pack2(pv[8 * s2 + 0], pv[8 * s2 + 1], T);
-        u.y = pack2(pv[8 * s2 + 2], pv[8 * s2 + 3], T);
-        u.z = pack2(pv[8 * s2 + 4], pv[8 * s2 + 5], T);
-        u.w = pack2(pv[8 * s2 + 6], pv[8 * s2 + 7], T);
-        pf[k2][s2] = __builtin_bit_cast(s16x8, u);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = __builtin_amdgcn_exp2f(st[b][k2][r]);
+          l_run[b] += pv[r];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          uint4 u;
+          u.x = pack2(pv[8 * s2 + 0], pv[8 * s2 + 1], T);
+          u.y = pack2(pv[8 * s2 + 2], pv[8 * s2 + 3], T);
+          u.z = pack2(pv[8 * s2 + 4], pv[8 * s2 + 5], T);
+          u.w = pack2(pv[8 * s2 + 6], pv[8 * s2 + 7], T);
+          pf[b][k2][s2] = __builtin_bit_cast(s16x8, u);
+        }
       }
     }
     // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads, B = P^T (the S^T accumulator)
@@ -206,7 +265,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
           s16x8 vf;
           vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
           vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-          ot[d] = mfma32<T>(vf, pf[k2][s2], ot[d]);
+#pragma unroll
+          for (int b = 0; b < QB; ++b) ot[b][d] = mfma32<T>(vf, pf[b][k2][s2], ot[b][d]);
         }
       }
     if (t + 1 < ntiles) store_tile(cur ^ 1);
@@ -214,30 +274,31 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const WmAttnArgs p) {
   }
 
   // ---- epilogue: O[q][head*64 + d] = O^T / l
-  {
-    const float inv = 1.0f / xhalf_sum(l_run);
-    if (q_valid) {
-      u16* op = (u16*)p.O + ((size_t)(seq_row0 + qrow_l) * p.H + head) * 64;
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    const float inv = 1.0f / xhalf_sum(l_run[b]);
+    if (q_valid[b]) {
+      u16* op = (u16*)p.O + ((size_t)(seq_row0 + qrow[b]) * p.H + head) * 64;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           uint2 u;
-          u.x = pack2(ot[d][4 * g + 0] * inv, ot[d][4 * g + 1] * inv, T);
-          u.y = pack2(ot[d][4 * g + 2] * inv, ot[d][4 * g + 3] * inv, T);
+          u.x = pack2(ot[b][d][4 * g + 0] * inv, ot[b][d][4 * g + 1] * inv, T);
+          u.y = pack2(ot[b][d][4 * g + 2] * inv, ot[b][d][4 * g + 3] * inv, T);
           *(uint2*)(op + 32 * d + 8 * g + 4 * h) = u;
         }
     }
   }
 }
 
-template <int T, int NW>
+template <int T, int NW, int QB, int MINW>
 hipError_t launch(const WmAttnArgs& a, hipStream_t s) {
-  constexpr int QT = NW * 32;
+  constexpr int QT = NW * 32 * QB;
   const int tiles_per_seq = (a.seq_len + QT - 1) / QT;
   const int nseq = a.q_rows / a.seq_len;
   dim3 grid(tiles_per_seq * nseq * a.H), block(NW * 64);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NW>), grid, block, 0, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW>), grid, block, 0, s, a);
   return hipGetLastError();
 }
 
@@ -246,5 +307,9 @@ hipError_t launch(const WmAttnArgs& a, hipStream_t s) {
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (a.q_rows <= 0) return hipSuccess;
   if (a.seq_len <= 0 || a.q_rows % a.seq_len != 0 || a.kv_chunks < 1) return hipErrorInvalidValue;
-  return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4>(a, s) : launch<WM_T_F16, 4>(a, s);
+  static const int forced = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
+  const int qb = forced ? forced : 3;  // 64 rows per wave at 2 waves/SIMD measured best on every shape
+  if (qb == 2) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 1>(a, s) : launch<WM_T_F16, 4, 2, 1>(a, s);
+  if (qb == 3) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s) : launch<WM_T_F16, 4, 2, 2>(a, s);
+  return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 2>(a, s) : launch<WM_T_F16, 4, 1, 2>(a, s);
 }

@@ -26,7 +26,7 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ attention (attention.hip)
 struct WmAttnArgs {
-  const void* Q; const void* K; const void* V;  // 16-bit [H][rows][64]; q pre-scaled by 1/8
+  const void* Q; const void* K; const void* V;  // 16-bit [H][rows][64]; q pre-scaled by log2(e)/sqrt(64): P = 2^(q.k - max)
   void* O;                                      // 16-bit [q_rows][H*64] token-major
   int H;
   int q_rows;          // total query rows (all sequences)

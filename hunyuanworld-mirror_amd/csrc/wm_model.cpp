@@ -711,7 +711,7 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     }
     if (rope) { a.rope_cos = B<float>(h, "rope_cos"); a.rope_sin = B<float>(h, "rope_sin"); }
     a.M = M; a.H = heads; a.head_stride = M; a.tokens_per_view = tokens_per_view; a.patch_start = patch_start; a.grid_w = d.gw;
-    a.q_scale = 0.125f; a.dtype = dt;
+    a.q_scale = 0.125f * 1.4426950408889634f; a.dtype = dt;  // 1/sqrt(64) * log2(e): the attention kernel works in base 2
     LCHK(c, wm_launch_qkv_post(a, c.s));
   }
   {

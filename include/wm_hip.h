@@ -102,6 +102,7 @@ wm_status wm_profile_read(wm_handle* h, int kind, double* total_ms, int64_t* lau
 /* ---- operator-level entry points (device pointers) used by the parity tests ---- */
 wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, const float* gamma,
                      int M, int N, int K, void* stream);
+/* Q must be pre-scaled by log2(e)/sqrt(64) (what wm_op_qkv_post does with q_scale): softmax is evaluated in base 2 */
 wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
                           int kv_chunks, int kv_rows_per_chunk, void* stream);
 wm_status wm_op_layernorm(const float* x, void* y, const float* w, const float* b, int rows, int D, float eps, int out_f32,

@@ -88,9 +88,12 @@ def test_gemm_identity_asymmetric(dev):
     assert torch.equal(out, W.float().t())
 
 
+LOG2E = 1.4426950408889634
+
+
 def _attn_ref(q, k, v):
-    # q,k,v [H, L, 64] fp32 (q already scaled)
-    a = torch.softmax(q @ k.transpose(-1, -2), -1)
+    # q,k,v [H, L, 64] fp32; q carries log2(e)/sqrt(d) (the kernel evaluates softmax in base 2)
+    a = torch.softmax((q @ k.transpose(-1, -2)) * math.log(2.0), -1)
     return a @ v
 
 
@@ -99,7 +102,7 @@ def _attn_ref(q, k, v):
 def test_attention(dev, H, nseq, L, dt):
     g = torch.Generator().manual_seed(H * 1000 + L)
     M = nseq * L
-    q = _t16(torch.randn(H, M, 64, generator=g) * 0.125 * 1.5, dt).to(dev)
+    q = _t16(torch.randn(H, M, 64, generator=g) * 0.125 * 1.5 * LOG2E, dt).to(dev)
     k = _t16(torch.randn(H, M, 64, generator=g) * 1.5, dt).to(dev)
     v = _t16(torch.randn(H, M, 64, generator=g), dt).to(dev)
     o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
@@ -121,7 +124,7 @@ def test_attention_spike_forces_rescale(dev):
     """Online-softmax rescale branch: one key far above the rest, placed in a late tile (guides rule 26)."""
     H, L = 2, 640
     g = torch.Generator().manual_seed(5)
-    q = torch.randn(H, L, 64, generator=g) * 0.125
+    q = torch.randn(H, L, 64, generator=g) * 0.125 * LOG2E
     k = torch.randn(H, L, 64, generator=g)
     v = torch.randn(H, L, 64, generator=g)
     k[:, 500] = q[:, 17] * 8 * 40.0  # row 17's score with key 500 is huge
@@ -136,11 +139,31 @@ def test_attention_spike_forces_rescale(dev):
     assert _rel(got, ref) < 8e-3
 
 
+def test_attention_all_scores_far_below_zero(dev):
+    """Every score is << 0 from the first tile on: the running max must still be tracked (first-tile forced
+    update), otherwise every P underflows and O = 0/0."""
+    H, L = 2, 200
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(H, 1, 64, generator=g)
+    q = (base + 0.05 * torch.randn(H, L, 64, generator=g)) * 3.0
+    k = -(base + 0.05 * torch.randn(H, L, 64, generator=g)) * 3.0   # q.k ~ -9 * |base|^2 ~ -600 (log2 units)
+    v = torch.randn(H, L, 64, generator=g)
+    q, k, v = [_t16(x, BF16).to(dev) for x in (q, k, v)]
+    o = torch.empty(L, H * 64, device=dev, dtype=torch.int16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_attention(BF16, _p(q), _p(k), _p(v), _p(o), H, L, L, 1, 0, s) == 0
+    torch.cuda.synchronize()
+    got = _from16(o, BF16).reshape(L, H, 64)
+    ref = _attn_ref(q.float(), k.float(), v.float()).transpose(0, 1)
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) < 1e-2
+
+
 def test_attention_kv_chunks_equals_concat(dev):
     """Sharded global attention: keys/values given as 2 gathered chunks == one concatenated sequence."""
     H, Lq, Lc = 4, 300, 300
     g = torch.Generator().manual_seed(9)
-    q = _t16(torch.randn(H, Lq, 64, generator=g) * 0.125, BF16).to(dev)
+    q = _t16(torch.randn(H, Lq, 64, generator=g) * 0.125 * LOG2E, BF16).to(dev)
     kc = _t16(torch.randn(2, H, Lc, 64, generator=g), BF16).to(dev)
     vc = _t16(torch.randn(2, H, Lc, 64, generator=g), BF16).to(dev)
     o = torch.empty(Lq, H * 64, device=dev, dtype=torch.int16)
