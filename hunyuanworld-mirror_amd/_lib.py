@@ -40,7 +40,8 @@ _FP = C.c_void_p  # device float*
 class wm_outputs(C.Structure):
     _fields_ = [(n, _FP) for n in (
         "camera_params", "camera_poses", "camera_intrs", "depth", "depth_conf", "pts3d", "pts3d_conf",
-        "normals", "normals_conf", "gs_depth", "gs_depth_conf", "gs_feat", "gs_params")] + [("taps", _FP * 4)]
+        "normals", "normals_conf", "gs_depth", "gs_depth_conf", "splat_means", "splat_quats", "splat_scales",
+        "splat_opacities", "splat_sh", "splat_weights")] + [("taps", _FP * 4)]
 
 
 EXPORTS = [

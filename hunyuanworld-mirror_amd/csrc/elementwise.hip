@@ -165,6 +165,64 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
   }
 }
 
+// Conv2d(3, C, 7, 1, 3) on the NCHW image as a GEMM (dense_head.py:91-95): row = pixel, col = c*49 + ky*7 + kx
+template <int T>
+__global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ img, u16* __restrict__ out, int N, int H, int W,
+                                                      int Kpad) {
+  const size_t total = (size_t)N * H * W * Kpad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % Kpad);
+    const size_t r = i / Kpad;
+    float v = 0.f;
+    if (k < 147) {
+      const int c = k / 49, kk = k - c * 49, ky = kk / 7, kx = kk - ky * 7;
+      const int x = (int)(r % W), y = (int)((r / W) % H), n = (int)(r / ((size_t)W * H));
+      const int iy = y + ky - 3, ix = x + kx - 3;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)n * 3 + c) * H + iy) * W + ix];
+    }
+    out[i] = f2t<T>(v);
+  }
+}
+
+// prepare_splats (rasterization.py:389-498, position_from="gsdepth+predcamera"): activations
+// (act_gs.py), RGB->SH residual (sh_utils.py:112-113) and depth unprojection with the predicted
+// camera (geometry.py:5-89, closed-form SE3 inverse :95-110).  One thread per pixel.
+__global__ __launch_bounds__(256) void gs_splat_kernel(const float* __restrict__ gp, const float* __restrict__ img,
+                                                       const float* __restrict__ depth, const float* __restrict__ cam,
+                                                       float* __restrict__ means, float* __restrict__ quats,
+                                                       float* __restrict__ scales, float* __restrict__ opac,
+                                                       float* __restrict__ sh, float* __restrict__ wts, int N, int H, int W) {
+  const size_t npix = (size_t)N * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / ((size_t)W * H));
+    const float* g = gp + i * 12;
+    const float4 g0 = *(const float4*)g, g1 = *(const float4*)(g + 4), g2 = *(const float4*)(g + 8);
+    const float qn = sqrtf(g0.x * g0.x + g0.y * g0.y + g0.z * g0.z + g0.w * g0.w) + 1e-8f;
+    quats[i * 4 + 0] = g0.x / qn; quats[i * 4 + 1] = g0.y / qn; quats[i * 4 + 2] = g0.z / qn; quats[i * 4 + 3] = g0.w / qn;
+    scales[i * 3 + 0] = fminf(expf(g1.x), 0.3f); scales[i * 3 + 1] = fminf(expf(g1.y), 0.3f); scales[i * 3 + 2] = fminf(expf(g1.z), 0.3f);
+    opac[i] = 1.0f / (1.0f + expf(-g1.w));
+    const float C0 = 0.28209479177387814f;
+    const size_t hw = (size_t)H * W, p0 = (size_t)n * 3 * hw + (size_t)y * W + x;
+    sh[i * 3 + 0] = (img[p0] - 0.5f) / C0 + g2.x;
+    sh[i * 3 + 1] = (img[p0 + hw] - 0.5f) / C0 + g2.y;
+    sh[i * 3 + 2] = (img[p0 + 2 * hw] - 0.5f) / C0 + g2.z;
+    wts[i] = 1.0f / (1.0f + expf(-g2.w));
+    // camera: [t, quat xyzw, fov_v, fov_u] is w2c; c2w = [R^T | -R^T t]
+    const float* v = cam + n * 9;
+    const float qi = v[3], qj = v[4], qk = v[5], qr = v[6];
+    const float s2 = 2.0f / (qi * qi + qj * qj + qk * qk + qr * qr);
+    const float R[9] = {1 - s2 * (qj * qj + qk * qk), s2 * (qi * qj - qk * qr), s2 * (qi * qk + qj * qr),
+                        s2 * (qi * qj + qk * qr), 1 - s2 * (qi * qi + qk * qk), s2 * (qj * qk - qi * qr),
+                        s2 * (qi * qk - qj * qr), s2 * (qj * qk + qi * qr), 1 - s2 * (qi * qi + qj * qj)};
+    const float fy = H * 0.5f / tanf(v[7] * 0.5f), fx = W * 0.5f / tanf(v[8] * 0.5f);
+    const float d = depth[i];
+    const float xc = ((float)x - W * 0.5f) * d / fx, yc = ((float)y - H * 0.5f) * d / fy, zc = d;
+    float tc[3];
+    for (int a = 0; a < 3; ++a) tc[a] = -(R[0 * 3 + a] * v[0] + R[1 * 3 + a] * v[1] + R[2 * 3 + a] * v[2]);
+    for (int a = 0; a < 3; ++a) means[i * 3 + a] = R[0 * 3 + a] * xc + R[1 * 3 + a] * yc + R[2 * 3 + a] * zc + tc[a];
+  }
+}
+
 // ------------------------------------------------------------------------------------------ tokens
 // vision_transformer.py:215-219: cls + pos[0], then R registers (patch rows are written by the
 // patchify GEMM epilogue with pos[1+j] added).
@@ -327,6 +385,22 @@ hipError_t wm_launch_im2col(const float* img, void* out, int N, int C, int H, in
     hipLaunchKernelGGL(im2col_kernel<WM_T_BF16>, dim3(grid_for(total)), dim3(256), 0, s, img, (u16*)out, N, C, H, W, ps, Kpad, normalize);
   else
     hipLaunchKernelGGL(im2col_kernel<WM_T_F16>, dim3(grid_for(total)), dim3(256), 0, s, img, (u16*)out, N, C, H, W, ps, Kpad, normalize);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_im2col7(const float* img, void* out, int N, int H, int W, int Kpad, int dtype, hipStream_t s) {
+  const size_t total = (size_t)N * H * W * Kpad;
+  if (!total) return hipSuccess;
+  if (dtype == WM_T_BF16) hipLaunchKernelGGL(im2col7_kernel<WM_T_BF16>, dim3(grid_for(total)), dim3(256), 0, s, img, (u16*)out, N, H, W, Kpad);
+  else hipLaunchKernelGGL(im2col7_kernel<WM_T_F16>, dim3(grid_for(total)), dim3(256), 0, s, img, (u16*)out, N, H, W, Kpad);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_gs_splat(const float* gp, const float* img, const float* depth, const float* cam, float* means, float* quats,
+                              float* scales, float* opac, float* sh, float* wts, int N, int H, int W, hipStream_t s) {
+  if (!N) return hipSuccess;
+  hipLaunchKernelGGL(gs_splat_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, s, gp, img, depth, cam, means, quats, scales,
+                     opac, sh, wts, N, H, W);
   return hipGetLastError();
 }
 

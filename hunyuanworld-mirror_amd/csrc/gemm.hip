@@ -189,6 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
             if (!ok[g]) continue;
             const int col = cb + 8 * g;
             float4 x = v[g];
+            if (p.relu) x = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
             if (p.add) {
               const float4 ad = *(const float4*)(p.add + (size_t)q * p.N + col);
               x.x += ad.x; x.y += ad.y; x.z += ad.z; x.w += ad.w;

@@ -19,7 +19,7 @@ struct WmGemmArgs {
   const float* bias; const float* gamma; const float* add;
   int M, N, K, lda, ldw, ldc;
   int dtype, epi;
-  int rows_per_group, out_group, out_off, accumulate, out16;  // WM_EPI_ROWMAP_ADD (out16: C is 16-bit, no accumulate)
+  int rows_per_group, out_group, out_off, accumulate, out16, relu;  // WM_EPI_ROWMAP_ADD (out16: C is 16-bit, no accumulate; relu before add)
   int ct_k, ct_cout, ct_gh, ct_gw;                     // WM_EPI_CONVT
 };
 hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s);
@@ -65,6 +65,11 @@ hipError_t wm_launch_qkv_post(const WmQkvArgs& a, hipStream_t s);
 // images f32 [N][C][H][W] -> im2col rows [N*gh*gw][Kpad] 16-bit, (x-mean)/std per channel when norm
 hipError_t wm_launch_im2col(const float* img, void* out, int N, int C, int H, int W, int ps, int Kpad,
                             int normalize, int dtype, hipStream_t s);
+// 7x7 pad-3 im2col of the NCHW image: [N*H*W][Kpad] 16-bit, col = c*49 + ky*7 + kx
+hipError_t wm_launch_im2col7(const float* img, void* out, int N, int H, int W, int Kpad, int dtype, hipStream_t s);
+// Gaussian-splat assembly per pixel from raw params [npix][12], image, gs_depth and predicted cameras [N][9]
+hipError_t wm_launch_gs_splat(const float* gp, const float* img, const float* depth, const float* cam, float* means, float* quats,
+                              float* scales, float* opac, float* sh, float* wts, int N, int H, int W, hipStream_t s);
 // DINO tokens: X[n][0]=cls+pos[0]; X[n][1..R]=reg; X[n][1+R+j] = patch[n][j] + pos[1+j]   (f32)
 hipError_t wm_launch_dino_tokens(const float* patch, const float* cls, const float* reg, const float* pos,
                                  float* X, int N, int hw, int R, int D, hipStream_t s);

@@ -117,7 +117,8 @@ WKind classify(const std::string& n, int ndim) {
   }
   const bool head = starts_with(n, "pts_head.") || starts_with(n, "depth_head.") || starts_with(n, "norm_head.") || starts_with(n, "gs_head.");
   if (head && ndim == 4 && ends_with(n, ".weight")) {
-    if (ends_with(n, "scratch.output_conv2.2.weight") || n.find("input_merger") != std::string::npos) return WK_F32;
+    if (ends_with(n, "scratch.output_conv2.2.weight")) return WK_F32;
+    if (n.find("input_merger") != std::string::npos) return WK_LIN16_HEAD;  // 7x7 conv on the image as a GEMM, K = 3*49
     if (n.find("resize_layers.0.") != std::string::npos || n.find("resize_layers.1.") != std::string::npos) return WK_CONVT16_HEAD;
     if (n.find(".projects.") != std::string::npos) return WK_LIN16_HEAD;
     return WK_CONV16_HEAD;
@@ -303,7 +304,9 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("dpt_rn2", ch * 4 * hw * Fm * 4);
   add("dpt_rn3", ch * hw * Fm * 4);
   add("dpt_rn4", ch * (size_t)d.gh2 * d.gw2 * Fm * 4);
-  const size_t big = ch * std::max<size_t>({64 * hw * (size_t)Fm, (size_t)d.H * d.W * (Fm / 2), (size_t)d.H * d.W * 32}) * 4;
+  const size_t big = ch * std::max<size_t>({64 * hw * (size_t)Fm, (size_t)d.H * d.W * (Fm / 2), (size_t)d.H * d.W * 32,
+                                            c.enable_gs ? (size_t)d.H * d.W * c.gs_dim : 0}) * 4;
+  if (c.enable_gs) add("gs_im2col", ch * (size_t)d.H * d.W * 192 * 2);
   for (int i = 0; i < 4; ++i) add(("dpt_s" + std::to_string(i)).c_str(), big);
   for (int i = 0; i < 4; ++i) add(("dpt_pos" + std::to_string(i)).c_str(), hw * oc[i] * 4);
   add("dpt_posx", (size_t)d.W * (Fm / 4) * 4 * 2);  // one table per feature width (F/2 channels -> F/4 per axis)
@@ -833,7 +836,7 @@ wm_status rcu(Ctx& c, const std::string& p, const float* x, const float* extra, 
 
 // DPTHead (dense_head.py:107-295) for views [v0, v0+n) of this rank
 wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, bool is_gs, float* out_attr, float* out_conf,
-                   const float* img, float* gs_feat, float* gs_params) {
+                   const float* img, const wm_outputs* out, int first_view) {
   wm_handle* h = c.h;
   const Dims& d = c.d;
   const wm_config& cf = h->cfg;
@@ -923,7 +926,28 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     const size_t npix = (size_t)n * Ho * Wo, voff = (size_t)v0 * Ho * Wo;
     LCHK(c, wm_launch_dpt_tail(others[2], F(h, sc + "output_conv2.2.weight"), F(h, sc + "output_conv2.2.bias"),
                                out_attr + voff * (out_dim - 1), out_conf + voff, npix, out_dim, act, c.s));
-    (void)img; (void)gs_feat; (void)gs_params;
+    if (is_gs && out->splat_means) {
+      // dense_head.py:232-244: fused += ReLU(conv7x7(img)); then GaussianSplatRenderer.gs_head
+      // (rasterization.py:149-153): conv3x3 (no bias) -> ReLU -> conv1x1 -> 12 raw parameters per pixel
+      const float* img_c = img + (size_t)v0 * 3 * Ho * Wo;
+      void* col = B<void>(h, "gs_im2col");
+      LCHK(c, wm_launch_im2col7(img_c, col, n, Ho, Wo, 192, c.hdt, c.s));
+      WmGemmArgs ex;
+      memset(&ex, 0, sizeof(ex));
+      ex.rows_per_group = (int)npix; ex.accumulate = 1; ex.relu = 1;
+      st = gemm(c, c.hdt, WM_EPI_ROWMAP_ADD, col, 192, W16(h, p + "input_merger.0.weight"), 192, fused, F_ / 2,
+                F(h, p + "input_merger.0.bias"), nullptr, (int)npix, F_ / 2, 192, &ex);
+      if (st) return st;
+      float* X = others[0];   // [n][H][W][gs_dim]
+      float* gp = others[2];  // [n*H*W][12] (y32 is dead after the tail)
+      st = conv(c, fused, "gs_renderer.gs_head.0", false, nullptr, false, nullptr, X, n, Ho, Wo, 3, 1, 1, false);
+      if (st) return st;
+      st = conv(c, X, "gs_renderer.gs_head.2", true, nullptr, false, nullptr, gp, n, Ho, Wo, 1, 1, 0, true);
+      if (st) return st;
+      LCHK(c, wm_launch_gs_splat(gp, img_c, out_attr + voff, B<float>(h, "cam_params") + (size_t)(first_view + v0) * 9,
+                                 out->splat_means + voff * 3, out->splat_quats + voff * 4, out->splat_scales + voff * 3,
+                                 out->splat_opacities + voff, out->splat_sh + voff * 3, out->splat_weights + voff, n, Ho, Wo, c.s));
+    }
   }
   return WM_OK;
 }
@@ -1030,19 +1054,22 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   }
   // ---- a13: DPT heads (worldmirror.py:74-98)
   if (cf.enable_depth && out->depth && out->depth_conf) {
-    st = dpt_head(c, "depth_head.", cf.dpt_features, 2, WM_ACT_EXP, false, out->depth, out->depth_conf, img, nullptr, nullptr);
+    st = dpt_head(c, "depth_head.", cf.dpt_features, 2, WM_ACT_EXP, false, out->depth, out->depth_conf, img, out, first_view);
     if (st) return st;
   }
   if (cf.enable_pts && out->pts3d && out->pts3d_conf) {
-    st = dpt_head(c, "pts_head.", cf.dpt_features, 4, WM_ACT_INV_LOG, false, out->pts3d, out->pts3d_conf, img, nullptr, nullptr);
+    st = dpt_head(c, "pts_head.", cf.dpt_features, 4, WM_ACT_INV_LOG, false, out->pts3d, out->pts3d_conf, img, out, first_view);
     if (st) return st;
   }
   if (cf.enable_norm && out->normals && out->normals_conf) {
-    st = dpt_head(c, "norm_head.", cf.dpt_features, 4, WM_ACT_NORM, false, out->normals, out->normals_conf, img, nullptr, nullptr);
+    st = dpt_head(c, "norm_head.", cf.dpt_features, 4, WM_ACT_NORM, false, out->normals, out->normals_conf, img, out, first_view);
     if (st) return st;
   }
   if (cf.enable_gs && out->gs_depth && out->gs_depth_conf) {
-    st = dpt_head(c, "gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf, img, out->gs_feat, out->gs_params);
+    if (out->splat_means && !(out->splat_quats && out->splat_scales && out->splat_opacities && out->splat_sh && out->splat_weights))
+      return fail(h, WM_ERR_INVALID, "splat outputs must be given together");
+    if (out->splat_means && !(cf.enable_cam && out->camera_params)) return fail(h, WM_ERR_INVALID, "splats need the camera head");
+    st = dpt_head(c, "gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf, img, out, first_view);
     if (st) return st;
   }
   return WM_OK;

@@ -90,6 +90,33 @@ def extract_priors(views: Dict[str, torch.Tensor]):
     return depths, rays, poses
 
 
+def prune_gs(splats: Dict[str, torch.Tensor], voxel_size: float = 0.002) -> Dict[str, List[torch.Tensor]]:
+    """Weighted voxel merge of the per-pixel splats (rasterization.py:301-387).  Post-path geometry
+    (SURVEY §8f rank 2): torch ops on the device for now; everything before it runs in HIP."""
+    out = {k: [] for k in ("means", "sh", "opacities", "scales", "quats")}
+    for i in range(splats["means"].shape[0]):
+        mean, w = splats["means"][i], splats["weights"][i]
+        vi = (mean / voxel_size).floor().long()
+        vi = vi - vi.min(0)[0]
+        dims = vi.max(0)[0] + 1
+        flat = vi[:, 0] * dims[1] * dims[2] + vi[:, 1] * dims[2] + vi[:, 2]
+        uniq, inv = torch.unique(flat, return_inverse=True)
+        K = uniq.numel()
+        wsum = torch.zeros(K, device=w.device).scatter_add_(0, inv, w).clamp(min=1e-8)
+
+        def wavg(x):
+            acc = torch.zeros((K,) + x.shape[1:], device=x.device)
+            acc.index_add_(0, inv, x * w.reshape((-1,) + (1,) * (x.dim() - 1)))
+            return acc
+        out["means"].append(wavg(mean) / wsum[:, None])
+        out["sh"].append(wavg(splats["sh"][i]) / wsum[:, None, None])
+        out["opacities"].append(torch.zeros(K, device=w.device).scatter_add_(0, inv, w * w) / wsum)
+        out["scales"].append(wavg(splats["scales"][i]) / wsum[:, None])
+        q = wavg(splats["quats"][i])
+        out["quats"].append(q / q.norm(dim=1, keepdim=True).clamp(min=1e-8))
+    return out
+
+
 class _GSRendererStub:
     """Placeholder for ``model.gs_renderer`` (infer.py:264): rasterisation is out of scope."""
 
@@ -127,6 +154,7 @@ class WorldMirror:
         self._comm = None  # (rank, world)
         self.training = False
         self.return_taps = False
+        self.enable_prune = True  # GaussianSplatRenderer(enable_prune=True), worldmirror.py:113
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -313,8 +341,8 @@ class WorldMirror:
         if self.cfg.enable_gs:
             alloc("gs_depth", "gs_depth", (1, n, H, W, 1))
             alloc("gs_depth_conf", "gs_depth_conf", (1, n, H, W))
-            alloc("gs_feat", "gs_feat", (1, n, H, W, self.cfg.gs_dim // 2))
-            alloc("gs_params", "gs_params", (1, n, H, W, 12))
+            for key, ch in (("means", 3), ("quats", 4), ("scales", 3), ("opacities", 0), ("sh", 3), ("weights", 0)):
+                alloc("_splat_" + key, "splat_" + key, (1, n, H, W, ch) if ch else (1, n, H, W))
         taps = None
         if self.return_taps:
             P = self.cfg.patch_start_idx + (H // ps) * (W // ps)
@@ -333,6 +361,14 @@ class WorldMirror:
             raise RuntimeError(f"wm_forward failed ({st}): {self._err()}")
         if taps is not None:
             res["taps"] = taps
+        if self.cfg.enable_gs:
+            raw = {k: res.pop("_splat_" + k) for k in ("means", "quats", "scales", "opacities", "sh", "weights")}
+            M = n * H * W
+            raw = {"means": raw["means"].reshape(1, M, 3), "quats": raw["quats"].reshape(1, M, 4),
+                   "scales": raw["scales"].reshape(1, M, 3), "opacities": raw["opacities"].reshape(1, M),
+                   "sh": raw["sh"].reshape(1, M, 1, 3), "weights": raw["weights"].reshape(1, M)}
+            res["splats_raw"] = raw
+            res["splats"] = prune_gs(raw) if self.enable_prune else raw
         self._keepalive = (img_l, pose_l, ray_l, depth_l)
         return res
 

@@ -54,8 +54,13 @@ typedef struct {
   float* normals_conf;  /* [N][H][W]    */
   float* gs_depth;      /* [N][H][W][1] */
   float* gs_depth_conf; /* [N][H][W]    */
-  float* gs_feat;       /* [N][H][W][gs_dim/2] NHWC fused GS feature (dense_head.py:232-244) */
-  float* gs_params;     /* [N][H][W][12] raw gaussian parameters (rasterization.py:149-153)  */
+  /* Gaussian splats before voxel pruning (rasterization.py:389-498), one per pixel of the local views */
+  float* splat_means;     /* [N][H][W][3] */
+  float* splat_quats;     /* [N][H][W][4] */
+  float* splat_scales;    /* [N][H][W][3] */
+  float* splat_opacities; /* [N][H][W]    */
+  float* splat_sh;        /* [N][H][W][3] (sh degree 0) */
+  float* splat_weights;   /* [N][H][W]    */
   float* taps[4];       /* optional: the 4 backbone taps [N][P][2*D] (visual_transformer.py:337-339) */
 } wm_outputs;
 

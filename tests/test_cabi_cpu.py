@@ -34,7 +34,7 @@ def test_exports_match_header(L):
 def test_config_struct_layout_matches_header():
     from hunyuanworld_mirror_amd import _lib
     assert C.sizeof(_lib.wm_config) == 4 * (4 + 6 + 4 + 4 + 1 + 2 + 3 + 1 + 4 + 2)
-    assert C.sizeof(_lib.wm_outputs) == 8 * 17
+    assert C.sizeof(_lib.wm_outputs) == 8 * 21
 
 
 @pytest.mark.parametrize("gh,gw", [(5, 4), (4, 5), (3, 3), (16, 16), (7, 5)])
