@@ -13,6 +13,8 @@
 #include "wm_common.h"
 #include "wm_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -205,8 +207,13 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+bool wm_conv3x3_applicable(const WmConvArgs& a);
+hipError_t wm_launch_conv3x3(const WmConvArgs& a, hipStream_t s);
+
 hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s) {
   if (a.N <= 0) return hipSuccess;
+  static const bool no_halo = getenv("WM_CONV_GENERIC") != nullptr;
+  if (!no_halo && wm_conv3x3_applicable(a)) return wm_launch_conv3x3(a, s);
   if (a.Cin % 32 != 0 || a.ksize < 1) return hipErrorInvalidValue;
   if (a.Ho != (a.Hi + 2 * a.pad - a.ksize) / a.stride + 1 || a.Wo != (a.Wi + 2 * a.pad - a.ksize) / a.stride + 1)
     return hipErrorInvalidValue;

@@ -1,0 +1,221 @@
+// 3x3 / stride 1 / pad 1 NHWC convolution with halo reuse — the dominant DPT-head operator
+// (reference: src/models/heads/dense_head.py ResidualConvUnit :426-455, scratch.layer*_rn :394-406,
+//  output_conv1 / output_conv2[0] :97-105; 95 % of the heads' 298.6 GFLOP/view).
+//
+// A block owns a 16x16 output patch (256 pixels) x BN output channels of one image.  Per 64-channel
+// chunk the 18x18 input halo is staged ONCE into LDS (fp32 -> 16-bit, optional ReLU, zero padding)
+// and then feeds all 9 taps: every tap's MFMA A-rows are the same LDS image read at a shifted row.
+// The generic implicit-GEMM kernel (conv.hip) re-fetches and re-converts every input pixel 9 times.
+// Weights [Cout][ky][kx][Cin] stream per (chunk, tap) by LDS-DMA, double buffered.  MFMA operands are
+// swapped (D = W_frag * X_frag) so a lane owns a pixel and 4 consecutive channels: float4 epilogue
+// with bias + relu?(resid) + resid2 (RCU skip and fusion add).
+#include "wm_common.h"
+#include "wm_kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+constexpr int TP = 16;                      // patch edge
+constexpr int HW_ = TP + 2;                 // halo edge (18)
+constexpr int HROWS = HW_ * HW_;            // 324 halo pixels
+constexpr int HALO_BYTES = HROWS * 128;     // 64 channels x 2 B per pixel
+constexpr int HCH = HROWS * 8;              // 16-B chunks per halo
+constexpr int HPT = (HCH + 511) / 512;      // chunks per thread (6)
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
+  constexpr int BN = WN * TN * 32;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int PB = BN / 8;  // 1-KiB LDS-DMA pieces per weight tile
+  static_assert(WM * WN == 8 && WM * TM * 32 == 256, "8 waves x 256 pixels");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 halo][2 B]
+  char* hbuf = smem;
+  char* bbuf = smem + 2 * HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int H = p.Hi, W = p.Wi, Cin = p.Cin, Cout = p.Cout;
+  const int tiles_x = (W + TP - 1) / TP, tiles_y = (H + TP - 1) / TP, ctiles = (Cout + BN - 1) / BN;
+  const int nblk = p.N * tiles_y * tiles_x * ctiles;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  const int ct = lid % ctiles; lid /= ctiles;
+  const int tx = lid % tiles_x; lid /= tiles_x;
+  const int ty = lid % tiles_y;
+  const int n = lid / tiles_y;
+  const int y0 = ty * TP, x0 = tx * TP, n0 = ct * BN;
+  const float* xin = p.x + (size_t)n * H * W * Cin;
+  const u16* Wt = (const u16*)p.w;
+  const int K = 9 * Cin;
+
+  // ---- halo staging (global fp32 -> regs -> 16-bit LDS)
+  float4 hreg[HPT][2];
+  auto halo_load = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int id = tid + i * 512;
+      const int hr = id >> 3, ch = id & 7;
+      const int hy = hr / HW_, hx = hr - hy * HW_;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      if (id < HCH && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const float* s = xin + ((size_t)iy * W + ix) * Cin + cc * 64 + ch * 8;
+        hreg[i][0] = *(const float4*)s;
+        hreg[i][1] = *(const float4*)(s + 4);
+      } else {
+        hreg[i][0] = make_float4(0, 0, 0, 0);
+        hreg[i][1] = make_float4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto halo_store = [&](char* dst) {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int id = tid + i * 512;
+      if (id >= HCH) continue;
+      const int hr = id >> 3, ch = id & 7;
+      float v[8] = {hreg[i][0].x, hreg[i][0].y, hreg[i][0].z, hreg[i][0].w, hreg[i][1].x, hreg[i][1].y, hreg[i][1].z, hreg[i][1].w};
+      if (p.relu_in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      uint4 u;
+      u.x = (uint32_t)f2t<T>(v[0]) | ((uint32_t)f2t<T>(v[1]) << 16);
+      u.y = (uint32_t)f2t<T>(v[2]) | ((uint32_t)f2t<T>(v[3]) << 16);
+      u.z = (uint32_t)f2t<T>(v[4]) | ((uint32_t)f2t<T>(v[5]) << 16);
+      u.w = (uint32_t)f2t<T>(v[6]) | ((uint32_t)f2t<T>(v[7]) << 16);
+      *(uint4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = u;
+    }
+  };
+  // ---- weight tile (chunk cc, tap) by LDS-DMA, swizzle on the source address
+  auto stage_w = [&](int cc, int tap, char* dst) {
+    for (int pc = wave; pc < PB; pc += 8) {
+      const int r = pc * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz(r);
+      int co = n0 + r;
+      co = co < Cout ? co : Cout - 1;
+      __builtin_amdgcn_global_load_lds((glb_vp)(Wt + (size_t)co * K + tap * Cin + cc * 64 + c * 8), (lds_vp)(dst + pc * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane halo row of the patch pixel this lane feeds into MFMA tile i (tap offset added later)
+  int hbase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = (wm * TM + i) * 32 + (lane & 31);
+    hbase[i] = (r >> 4) * HW_ + (r & 15);
+  }
+
+  const int nchunks = Cin / 64;
+  halo_load(0);
+  stage_w(0, 0, bbuf);
+  halo_store(hbuf);
+  int kt = 0;
+  for (int cc = 0; cc < nchunks; ++cc) {
+    const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
+    for (int tap = 0; tap < 9; ++tap, ++kt) {
+      __syncthreads();  // weights(kt) landed (vmcnt 0), halo writes visible, previous tile's reads done
+      const bool last = cc + 1 == nchunks && tap == 8;
+      if (!last) stage_w(tap == 8 ? cc + 1 : cc, tap == 8 ? 0 : tap + 1, bbuf + ((kt + 1) & 1) * B_BYTES);
+      if (tap == 6 && cc + 1 < nchunks) halo_load(cc + 1);
+      const char* tB = bbuf + (kt & 1) * B_BYTES;
+      const int toff = (tap / 3) * HW_ + (tap % 3);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ch = 2 * ks + (lane >> 5);
+        s16x8 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int hr = hbase[i] + toff;
+          a[i] = *(const s16x8*)(hcur + hr * 128 + ((ch ^ swz(hr)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = (wn * TN + j) * 32 + (lane & 31);
+          b[j] = *(const s16x8*)(tB + row * 128 + ((ch ^ swz(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(b[j], a[i], acc[i][j]);  // D[cout][pixel]
+      }
+      if (tap == 8 && cc + 1 < nchunks) halo_store(hbuf + ((cc + 1) & 1) * HALO_BYTES);
+    }
+  }
+
+  // ---- epilogue: lane = pixel (lane&31) of tile i, regs 4g..4g+3 <-> channels 8g + 4h + {0..3}
+  const int h4 = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = (wm * TM + i) * 32 + (lane & 31);
+    const int y = y0 + (r >> 4), x = x0 + (r & 15);
+    if (y >= H || x >= W) continue;
+    const size_t obase = (((size_t)n * H + y) * W + x) * Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cb = n0 + (wn * TN + j) * 32 + h4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = cb + 8 * g;
+        if (col >= Cout) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (p.bias) {
+          const float4 bs = *(const float4*)(p.bias + col);
+          v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+        }
+        if (p.resid) {
+          float4 rr = *(const float4*)(p.resid + obase + col);
+          if (p.resid_relu) rr = make_float4(fmaxf(rr.x, 0.f), fmaxf(rr.y, 0.f), fmaxf(rr.z, 0.f), fmaxf(rr.w, 0.f));
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.resid2) {
+          const float4 rr = *(const float4*)(p.resid2 + obase + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        *(float4*)(p.y + obase + col) = v;
+      }
+    }
+  }
+}
+
+template <int T, int WM, int WN, int TM, int TN>
+hipError_t launch_cfg(const WmConvArgs& a, hipStream_t s) {
+  constexpr int BN = WN * TN * 32;
+  const size_t shm = 2 * HALO_BYTES + 2 * BN * 128;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr = true;
+  }
+  const int nblk = a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP) * ((a.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, TM, TN>), dim3(nblk), dim3(512), shm, s, a);
+  return hipGetLastError();
+}
+
+template <int T>
+hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
+  if (a.Cout > 128) return launch_cfg<T, 2, 4, 4, 2>(a, s);   // 256 px x 256 ch
+  if (a.Cout > 32) return launch_cfg<T, 4, 2, 2, 2>(a, s);    // 256 px x 128 ch
+  return launch_cfg<T, 8, 1, 1, 1>(a, s);                     // 256 px x 32 ch
+}
+
+}  // namespace
+
+bool wm_conv3x3_applicable(const WmConvArgs& a) {
+  return a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 64 == 0 && a.Cout % 4 == 0 && a.Hi * a.Wi >= 256;
+}
+
+hipError_t wm_launch_conv3x3(const WmConvArgs& a, hipStream_t s) {
+  return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, s) : launch_T<WM_T_F16>(a, s);
+}
