@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const WmConvArgs p) {
   load_a(0);
   stage_w<BK, BN>(W, K, n0, p.Cout, 0, smem + A_BYTES, wave, lane);
   store_a(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit LDS-DMA drain (see conv3x3.hip)
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const WmConvArgs p) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<T>(a[i], b[j], acc[i][j]);
     }
     if (kt + 1 < nk) store_a(nA);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }

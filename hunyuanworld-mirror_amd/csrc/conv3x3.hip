@@ -124,7 +124,10 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   for (int cc = 0; cc < nchunks; ++cc) {
     const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
     for (int tap = 0; tap < 9; ++tap, ++kt) {
-      __syncthreads();  // weights(kt) landed (vmcnt 0), halo writes visible, previous tile's reads done
+      // weights(kt) must have landed: hipcc does NOT reliably drain LDS-DMA before __syncthreads() here (it
+      // emitted lgkmcnt(0) only), so the vmcnt(0) is explicit.  Also publishes the halo writes.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       const bool last = cc + 1 == nchunks && tap == 8;
       if (!last) stage_w(tap == 8 ? cc + 1 : cc, tap == 8 ? 0 : tap + 1, bbuf + ((kt + 1) & 1) * B_BYTES);
       if (tap == 6 && cc + 1 < nchunks) halo_load(cc + 1);

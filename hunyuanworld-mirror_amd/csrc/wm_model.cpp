@@ -888,9 +888,11 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     // refinenet4: RCU2(rn4) -> resize to level 3 -> out_conv
     st = rcu(c, sc + "refinenet4.resConfUnit2.", rn[3], nullptr, S0, S1, n, Hs[3], Ws[3]);
     if (st) return st;
-    LCHK(c, wm_launch_bilinear(S1, S0, n, Hs[3], Ws[3], Hs[2], Ws[2], F_, nullptr, nullptr, c.s));
-    st = conv(c, S0, sc + "refinenet4.out_conv", true, nullptr, false, nullptr, S2, n, Hs[2], Ws[2], 1, 1, 0, false);
+    // out_conv (1x1) and the align_corners bilinear resize are both linear and the interpolation weights sum
+    // to 1, so out_conv(resize(x)) == resize(out_conv(x)): run the 1x1 at the LOW resolution (4x fewer FLOPs)
+    st = conv(c, S1, sc + "refinenet4.out_conv", true, nullptr, false, nullptr, S0, n, Hs[3], Ws[3], 1, 1, 0, false);
     if (st) return st;
+    LCHK(c, wm_launch_bilinear(S0, S2, n, Hs[3], Ws[3], Hs[2], Ws[2], F_, nullptr, nullptr, c.s));
     float* cur = S2;  // output of the previous fusion block at level L
     for (int L = 2; L >= 0; --L) {  // refinenet3 (level 2), refinenet2 (level 1), refinenet1 (level 0)
       const std::string rp = sc + "refinenet" + std::to_string(L + 1) + ".";
@@ -904,9 +906,9 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       st = rcu(c, rp + "resConfUnit2.", others[1], nullptr, others[0], others[2], n, Hs[L], Ws[L]);
       if (st) return st;
       const int Ho = L > 0 ? Hs[L - 1] : 2 * Hs[0], Wo = L > 0 ? Ws[L - 1] : 2 * Ws[0];
-      LCHK(c, wm_launch_bilinear(others[2], others[0], n, Hs[L], Ws[L], Ho, Wo, F_, nullptr, nullptr, c.s));
-      st = conv(c, others[0], rp + "out_conv", true, nullptr, false, nullptr, others[1], n, Ho, Wo, 1, 1, 0, false);
+      st = conv(c, others[2], rp + "out_conv", true, nullptr, false, nullptr, others[0], n, Hs[L], Ws[L], 1, 1, 0, false);
       if (st) return st;
+      LCHK(c, wm_launch_bilinear(others[0], others[1], n, Hs[L], Ws[L], Ho, Wo, F_, nullptr, nullptr, c.s));
       cur = others[1];
     }
     const int H8 = 8 * gh, W8 = 8 * gw;

@@ -236,7 +236,10 @@ def _conv_ref(x, w, b, stride, pad, relu_in, resid, resid_relu, resid2, dt):
 
 @pytest.mark.parametrize("Cin,Cout,ks,stride,Hh,Ww", [(64, 64, 3, 1, 20, 16), (256, 256, 3, 1, 37, 37), (32, 32, 3, 1, 70, 56),
                                                       (128, 32, 3, 1, 30, 30), (256, 256, 3, 2, 37, 37), (64, 64, 1, 1, 10, 8),
-                                                      (512, 256, 3, 1, 10, 10), (256, 128, 3, 1, 40, 40)])
+                                                      (512, 256, 3, 1, 10, 10), (256, 128, 3, 1, 40, 40),
+                                                      (1024, 256, 3, 1, 16, 16), (512, 256, 3, 1, 32, 32), (256, 256, 3, 1, 64, 64),
+                                                      (256, 128, 3, 1, 128, 128), (128, 32, 3, 1, 224, 224), (256, 256, 1, 1, 8, 8),
+                                                      (256, 256, 1, 1, 64, 64), (1024, 1024, 3, 2, 16, 16)])
 def test_conv(dev, Cin, Cout, ks, stride, Hh, Ww):
     dt = F16
     pad = 1 if ks == 3 else 0
