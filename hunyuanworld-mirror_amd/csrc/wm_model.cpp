@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -265,7 +266,7 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("O16", Mx * D * 2);
   add("H16", Mx * 4 * D * 2);
   for (int i = 0; i < 4; ++i) add(("tap" + std::to_string(i)).c_str(), Mv * 2 * D * 4);
-  if (d.world > 1) add("KVG", (size_t)d.world * 2 * Mv * D * 2);
+  add("KVG", (size_t)d.world * 2 * Mv * D * 2);
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("dino_pos", (size_t)(1 + d.hw) * D * 4);
@@ -721,7 +722,8 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     WmAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = Q16; a.O = O16; a.H = heads; a.q_rows = M; a.q_head_stride = M; a.dtype = dt;
-    if (is_global && d.world > 1) {
+    static const bool force_gather = getenv("WM_FORCE_GATHER") != nullptr;  // 1-rank test of the collective path
+    if (is_global && (d.world > 1 || (force_gather && h->comm.kind != 0))) {
       // K and V are adjacent: one all-gather of [K|V] per layer -> [world][2][H][M][64]
       char* KVG = B<char>(h, "KVG");
       st = comm_allgather(h, K16, KVG, 2 * hsz, c.s);

@@ -52,3 +52,31 @@ def test_two_virtual_ranks_match_single(name):
         assert rel_l2(res[r]["camera_params"].cpu().numpy(), ref["camera_params"].cpu().numpy()) < 2e-3
     del models
     L.wm_local_group_destroy(grp)
+
+
+def test_rccl_allgather_path_single_rank():
+    """The RCCL collective itself (ncclAllGather on the handle's own communicator) at world size 1:
+    WM_FORCE_GATHER routes global attention through the gathered-K/V path.  Run in a subprocess because
+    the switch is read once per process."""
+    import os, subprocess, sys
+    code = r"""
+import sys, ctypes as C, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from conftest import load_golden, rel_l2
+from hunyuanworld_mirror_amd import WorldMirror, _lib
+cfg, views, flags, outs, z = load_golden('tiny_2v_70x70_noprior')
+m = WorldMirror(arch=cfg).init_synthetic_weights().to('cuda:0')
+L = _lib.lib()
+ident = (C.c_uint8 * 128)()
+assert L.wm_rccl_unique_id(ident) == 0
+assert L.wm_comm_init_rccl(m._handle, ident, 0, 1) == 0, m._err()
+out = m({k: torch.from_numpy(v).cuda() for k, v in views.items()}, flags)
+torch.cuda.synchronize()
+e = rel_l2(out['pts3d'].cpu().numpy(), outs['pts3d'])
+print('rccl world-1 pts3d', e)
+assert e < 5e-3
+"""
+    env = dict(os.environ, WM_FORCE_GATHER="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    print(r.stdout[-500:], r.stderr[-1500:])
+    assert r.returncode == 0
