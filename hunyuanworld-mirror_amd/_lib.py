@@ -48,7 +48,7 @@ EXPORTS = [
     "wm_create", "wm_destroy", "wm_last_error", "wm_set_weight", "wm_finalize_weights", "wm_host_resample_pos",
     "wm_workspace_bytes", "wm_forward", "wm_forward_sharded", "wm_rccl_unique_id", "wm_comm_init_rccl",
     "wm_local_group_create", "wm_local_group_destroy", "wm_comm_init_local", "wm_profile_enable", "wm_profile_read",
-    "wm_op_gemm", "wm_op_attention", "wm_op_layernorm", "wm_op_qkv_post", "wm_op_conv", "wm_op_bilinear",
+    "wm_op_gemm", "wm_op_gemm_qkv", "wm_op_attention", "wm_op_layernorm", "wm_op_qkv_post", "wm_op_conv", "wm_op_bilinear",
     "wm_op_linear_f32", "wm_host_to_16",
 ]
 
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
     L.wm_profile_enable.argtypes = [vp, i32]
     L.wm_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.wm_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.wm_op_gemm_qkv.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     L.wm_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.wm_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]
     L.wm_op_qkv_post.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]

@@ -29,17 +29,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
 
-// Combine a value with the one held by lane ^ 32.  v_permlane32_swap exchanges lanes 32-63 of its
-// first operand with lanes 0-31 of its second; written as inline asm on two distinct registers
-// because hipcc folds the builtin's two results when both inputs are the same SSA value.
-// The s_nop covers the VALU-write -> permlane read hazard (guides T21).
-__device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
-  a = x; b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ float xhalf_max(float x) { float a, b; xhalf_pair(x, a, b); return fmaxf(a, b); }
-__device__ __forceinline__ float xhalf_sum(float x) { float a, b; xhalf_pair(x, a, b); return a + b; }
-
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;

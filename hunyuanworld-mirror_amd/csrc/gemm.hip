@@ -116,6 +116,104 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
 
   // ---------------- epilogue: lane (m = lane&31, h = lane>>5), reg 4g+e <-> col 8g + 4h + e ----------------
   const int h4 = (lane >> 5) * 4;
+  if constexpr (EPI == WM_EPI_QKV) {
+    // attention.py:50-56 fused: the wave's 64 columns are exactly one head of q, k or v (TN == 2, tiles
+    // aligned to 64): bias -> LayerNorm(64, eps 1e-5, affine) -> 2-D RoPE (rope.py:148-181) -> q scale ->
+    // 16-bit store in the head-major layout the attention kernel reads.  A lane holds 32 of its row's 64
+    // values (the other 32 sit in lane^32), and every RoPE pair (c, c+16) is lane-local (g <-> g+2).
+    static_assert(EPI != WM_EPI_QKV || TN == 2, "QKV epilogue needs 64 columns per wave");
+    const WmQkvArgs& q = p.qkv;
+    const int D = q.H * 64;
+    const int col0 = n0 + wn * 64;             // wave-uniform
+    const int which = col0 / D, head = (col0 - which * D) >> 6;
+    if (col0 < p.N) {
+      const float* nw = which == 0 ? q.qn_w : q.kn_w;
+      const float* nb = which == 0 ? q.qn_b : q.kn_b;
+      const bool do_norm = which < 2 && nw != nullptr;
+      const bool do_rope = which < 2 && q.rope_cos != nullptr;
+      u16* dst = (u16*)(which == 0 ? q.q : which == 1 ? q.k : q.v);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = m0 + (wm * TM + i) * 32 + (lane & 31);
+        const bool row_ok = row < p.M;
+        float v[2][4][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 bs = p.bias ? *(const float4*)(p.bias + col0 + 32 * j + 8 * g + h4) : make_float4(0, 0, 0, 0);
+            v[j][g][0] = acc[i][j][4 * g] + bs.x; v[j][g][1] = acc[i][j][4 * g + 1] + bs.y;
+            v[j][g][2] = acc[i][j][4 * g + 2] + bs.z; v[j][g][3] = acc[i][j][4 * g + 3] + bs.w;
+          }
+        if (do_norm) {
+          float sm = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sm += v[j][g][e];
+          const float mean = xhalf_sum(sm) * (1.0f / 64.0f);
+          float ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[j][g][e] -= mean; ss += v[j][g][e] * v[j][g][e]; }
+          const float rstd = 1.0f / sqrtf(xhalf_sum(ss) * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 w4 = *(const float4*)(nw + 32 * j + 8 * g + h4), b4 = *(const float4*)(nb + 32 * j + 8 * g + h4);
+              v[j][g][0] = v[j][g][0] * rstd * w4.x + b4.x; v[j][g][1] = v[j][g][1] * rstd * w4.y + b4.y;
+              v[j][g][2] = v[j][g][2] * rstd * w4.z + b4.z; v[j][g][3] = v[j][g][3] * rstd * w4.w + b4.w;
+            }
+        }
+        if (do_rope) {
+          const int rr = row_ok ? row : 0;
+          const int t = rr % q.tokens_per_view;
+          int py = 0, px = 0;
+          if (t >= q.patch_start) {
+            const int idx = t - q.patch_start;
+            py = idx / q.grid_w + 1;
+            px = idx - (py - 1) * q.grid_w + 1;
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int pos = j == 0 ? py : px;  // first 32 channels rotate by y, last 32 by x
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {      // pair (g, g+2): elements c and c+16; frequency index 8g + 4h + e
+              const float4 cs = *(const float4*)(q.rope_cos + pos * 16 + 8 * g + h4);
+              const float4 sn = *(const float4*)(q.rope_sin + pos * 16 + 8 * g + h4);
+              const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float lo = v[j][g][e], hi = v[j][g + 2][e];
+                v[j][g][e] = lo * c4[e] - hi * s4[e];
+                v[j][g + 2][e] = hi * c4[e] + lo * s4[e];
+              }
+            }
+          }
+        }
+        const float sc = which == 0 ? q.q_scale : 1.0f;
+        if (row_ok) {
+          u16* o = dst + ((size_t)head * q.head_stride + row) * 64 + h4;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              uint2 u;
+              u.x = (uint32_t)f2t<T>(v[j][g][0] * sc) | ((uint32_t)f2t<T>(v[j][g][1] * sc) << 16);
+              u.y = (uint32_t)f2t<T>(v[j][g][2] * sc) | ((uint32_t)f2t<T>(v[j][g][3] * sc) << 16);
+              *(uint2*)(o + 32 * j + 8 * g) = u;
+            }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = m0 + (wm * TM + i) * 32 + (lane & 31);
@@ -255,6 +353,7 @@ hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
     case WM_EPI_RESID: return launch_E<T, WM_EPI_RESID>(a, cfg, s);
     case WM_EPI_ROWMAP_ADD: return launch_E<T, WM_EPI_ROWMAP_ADD>(a, cfg, s);
     case WM_EPI_CONVT: return launch_E<T, WM_EPI_CONVT>(a, cfg, s);
+    case WM_EPI_QKV: return launch_E<T, WM_EPI_QKV>(a, cfg, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -286,7 +385,8 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.K <= 0 || a.K % BK != 0 || a.N % 4 != 0) return hipErrorInvalidValue;
   if ((a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;  // 16-B aligned rows
   if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
-  if (a.epi != WM_EPI_CONVT && (a.ldc & 3)) return hipErrorInvalidValue;
+  if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
+  if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
   const int cfg = pick_cfg(a);
   return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, cfg, s) : launch_T<WM_T_F16>(a, cfg, s);
 }

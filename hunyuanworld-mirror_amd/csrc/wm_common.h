@@ -51,6 +51,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Combine a value with the one held by lane ^ 32.  v_permlane32_swap exchanges lanes 32-63 of its
+// first operand with lanes 0-31 of its second; inline asm on two distinct registers because hipcc
+// folds the builtin's two results when both inputs are the same SSA value.  The s_nop covers the
+// VALU-write -> permlane-read hazard (guides T21).
+__device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xhalf_max(float x) { float a, b; xhalf_pair(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xhalf_sum(float x) { float a, b; xhalf_pair(x, a, b); return a + b; }
+
 // XCD-aware bijective block remap (guides T1): blocks b and b+8 share an XCD; give each XCD a
 // contiguous chunk of the logical tile space so neighbouring tiles hit the same L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -12,6 +12,17 @@ enum {
   WM_EPI_RESID = 3,       // C f32 += gamma[col] * (acc + bias)           (LayerScale + residual)
   WM_EPI_ROWMAP_ADD = 4,  // C f32 [row-remapped] (+)= acc + bias + add[row % rpg][col]
   WM_EPI_CONVT = 5,       // k==stride ConvTranspose2d pixel-shuffle scatter, NHWC f32 out
+  WM_EPI_QKV = 6,         // N = 3*D: bias, per-head LayerNorm(64) on q/k, 2-D RoPE, q scale, 16-bit [H][M][64] q/k/v
+};
+
+// qkv f32 [M][3*D] -> Q,K,V 16-bit [H][M][64] with optional per-head LayerNorm(64) and 2-D RoPE
+struct WmQkvArgs {
+  const float* qkv; void* q; void* k; void* v;
+  const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;  // null = no qk-norm
+  const float* rope_cos; const float* rope_sin;                                  // [max_pos][16], null = no rope
+  int M, H, head_stride;   // head_stride = rows per head in the outputs
+  int tokens_per_view, patch_start, grid_w;  // position of token t: special (0,0) or (y+1, x+1)
+  float q_scale; int dtype;
 };
 
 struct WmGemmArgs {
@@ -21,6 +32,7 @@ struct WmGemmArgs {
   int dtype, epi;
   int rows_per_group, out_group, out_off, accumulate, out16, relu;  // WM_EPI_ROWMAP_ADD (out16: C is 16-bit, no accumulate; relu before add)
   int ct_k, ct_cout, ct_gh, ct_gw;                     // WM_EPI_CONVT
+  WmQkvArgs qkv;                                       // WM_EPI_QKV (qkv.qkv unused; qkv.H*64 = D)
 };
 hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s);
 
@@ -51,15 +63,6 @@ struct WmLnArgs {
 };
 hipError_t wm_launch_layernorm(const WmLnArgs& a, hipStream_t s);
 
-// qkv f32 [M][3*D] -> Q,K,V 16-bit [H][M][64] with optional per-head LayerNorm(64) and 2-D RoPE
-struct WmQkvArgs {
-  const float* qkv; void* q; void* k; void* v;
-  const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;  // null = no qk-norm
-  const float* rope_cos; const float* rope_sin;                                  // [max_pos][16], null = no rope
-  int M, H, head_stride;   // head_stride = rows per head in the outputs
-  int tokens_per_view, patch_start, grid_w;  // position of token t: special (0,0) or (y+1, x+1)
-  float q_scale; int dtype;
-};
 hipError_t wm_launch_qkv_post(const WmQkvArgs& a, hipStream_t s);
 
 // images f32 [N][C][H][W] -> im2col rows [N*gh*gw][Kpad] 16-bit, (x-mean)/std per channel when norm

@@ -261,7 +261,6 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("Xd", (size_t)d.Md * D * 4);
   add("Xv", Mv * D * 4);
   add("A16", Mx * std::max<size_t>({D, (size_t)d.kpad_patch, (size_t)d.kpad_depth}) * 2);
-  add("QKV32", Mx * 3 * D * 4);
   add("QKV16", 3 * Mx * D * 2);
   add("O16", Mx * D * 2);
   add("H16", Mx * 4 * D * 2);
@@ -694,7 +693,6 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
   const Dims& d = c.d;
   const int D = d.D, dt = c.bdt;
   uint16_t* A16 = B<uint16_t>(h, "A16");
-  float* QKV32 = B<float>(h, "QKV32");
   char* QKV16 = B<char>(h, "QKV16");
   const size_t hsz = (size_t)M * D * 2;  // bytes of one of Q/K/V
   void* Q16 = QKV16; void* K16 = QKV16 + hsz; void* V16 = QKV16 + 2 * hsz;
@@ -703,12 +701,11 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
   wm_status st;
   st = layernorm(c, X, D, A16, D, F(h, p + "norm1.weight"), F(h, p + "norm1.bias"), D, eps, 1, M, 0, 0, 0, 0, 0, dt);
   if (st) return st;
-  st = gemm(c, dt, WM_EPI_F32, A16, D, W16(h, p + "attn.qkv.weight"), D, QKV32, 3 * D, F(h, p + "attn.qkv.bias"), nullptr, M, 3 * D, D);
-  if (st) return st;
-  {
-    WmQkvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.qkv = QKV32; a.q = Q16; a.k = K16; a.v = V16;
+  {  // QKV projection with q/k-norm + RoPE + head-major relayout fused into the epilogue (attention.py:50-56)
+    WmGemmArgs ex;
+    memset(&ex, 0, sizeof(ex));
+    WmQkvArgs& a = ex.qkv;
+    a.q = Q16; a.k = K16; a.v = V16;
     if (qk_norm) {
       a.qn_w = F(h, p + "attn.q_norm.weight"); a.qn_b = F(h, p + "attn.q_norm.bias");
       a.kn_w = F(h, p + "attn.k_norm.weight"); a.kn_b = F(h, p + "attn.k_norm.bias");
@@ -716,7 +713,8 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     if (rope) { a.rope_cos = B<float>(h, "rope_cos"); a.rope_sin = B<float>(h, "rope_sin"); }
     a.M = M; a.H = heads; a.head_stride = M; a.tokens_per_view = tokens_per_view; a.patch_start = patch_start; a.grid_w = d.gw;
     a.q_scale = 0.125f * 1.4426950408889634f; a.dtype = dt;  // 1/sqrt(64) * log2(e): the attention kernel works in base 2
-    LCHK(c, wm_launch_qkv_post(a, c.s));
+    st = gemm(c, dt, WM_EPI_QKV, A16, D, W16(h, p + "attn.qkv.weight"), D, nullptr, 0, F(h, p + "attn.qkv.bias"), nullptr, M, 3 * D, D, &ex);
+    if (st) return st;
   }
   {
     WmAttnArgs a;
@@ -1157,6 +1155,18 @@ extern "C" wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* W
   memset(&a, 0, sizeof(a));
   a.A = A; a.W = Wp; a.C = C; a.bias = bias; a.gamma = gamma; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N;
   a.dtype = dtype; a.epi = epi;
+  return wm_launch_gemm(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_gemm_qkv(int dtype, const void* A, const void* Wp, const float* bias, void* q, void* k, void* v,
+                                    const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, const float* rope_cos,
+                                    const float* rope_sin, int M, int H, int K, int tokens_per_view, int patch_start, int grid_w,
+                                    float q_scale, void* stream) {
+  WmGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.W = Wp; a.bias = bias; a.M = M; a.N = 3 * H * 64; a.K = K; a.lda = K; a.ldw = K; a.dtype = dtype; a.epi = WM_EPI_QKV;
+  a.qkv.q = q; a.qkv.k = k; a.qkv.v = v; a.qkv.qn_w = qn_w; a.qkv.qn_b = qn_b; a.qkv.kn_w = kn_w; a.qkv.kn_b = kn_b;
+  a.qkv.rope_cos = rope_cos; a.qkv.rope_sin = rope_sin; a.qkv.M = M; a.qkv.H = H; a.qkv.head_stride = M;
+  a.qkv.tokens_per_view = tokens_per_view; a.qkv.patch_start = patch_start; a.qkv.grid_w = grid_w; a.qkv.q_scale = q_scale; a.qkv.dtype = dtype;
   return wm_launch_gemm(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
 extern "C" wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,

@@ -107,6 +107,11 @@ wm_status wm_profile_read(wm_handle* h, int kind, double* total_ms, int64_t* lau
 /* ---- operator-level entry points (device pointers) used by the parity tests ---- */
 wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, const float* gamma,
                      int M, int N, int K, void* stream);
+/* QKV projection with the q/k-norm + 2-D RoPE + head-major relayout epilogue (attention.py:50-56): A [M][K] 16-bit,
+ * W [3*H*64][K] 16-bit -> q,k,v 16-bit [H][M][64] */
+wm_status wm_op_gemm_qkv(int dtype, const void* A, const void* W, const float* bias, void* q, void* k, void* v, const float* qn_w,
+                         const float* qn_b, const float* kn_w, const float* kn_b, const float* rope_cos, const float* rope_sin, int M,
+                         int H, int K, int tokens_per_view, int patch_start, int grid_w, float q_scale, void* stream);
 /* Q must be pre-scaled by log2(e)/sqrt(64) (what wm_op_qkv_post does with q_scale): softmax is evaluated in base 2 */
 wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
                           int kv_chunks, int kv_rows_per_chunk, void* stream);

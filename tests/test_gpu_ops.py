@@ -223,6 +223,46 @@ def test_qkv_post_matches_oracle(dev):
         assert e < 6e-4, nm
 
 
+@pytest.mark.parametrize("H,S,gh,gw", [(4, 2, 4, 5), (16, 2, 37, 37), (2, 3, 5, 4)])
+def test_gemm_qkv_fused_epilogue(dev, H, S, gh, gw):
+    """QKV GEMM with fused per-head LayerNorm + 2-D RoPE + relayout == oracle ops on the fp32 GEMM result."""
+    from oracle import worldmirror_ref as R
+    psi = 7
+    P = psi + gh * gw
+    M, D, K = S * P, H * 64, 128
+    g = torch.Generator().manual_seed(H + gh)
+    A = _t16(torch.randn(M, K, generator=g), BF16)
+    W = _t16(torch.randn(3 * D, K, generator=g) / math.sqrt(K), BF16)
+    bias = torch.randn(3 * D, generator=g) * 0.1
+    nw = [torch.randn(64, generator=g) for _ in range(4)]
+    qkv = A.float() @ W.float().t() + bias
+    cos_t, sin_t = R.rope_tables(max(gh, gw) + 1, 32, 100.0)
+    cos16, sin16 = cos_t[:, :16].contiguous(), sin_t[:, :16].contiguous()
+    yy, xx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos = torch.cat([torch.zeros(psi, 2, dtype=torch.long), torch.stack([yy.flatten(), xx.flatten()], -1) + 1], 0)
+    pos = pos[None].expand(S, -1, -1).reshape(1, M, 2)
+    t = qkv.reshape(1, M, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q = R.rope_2d(R.layer_norm(t[0], nw[0], nw[1], 1e-5), pos, 100.0) * 0.25
+    k = R.rope_2d(R.layer_norm(t[1], nw[2], nw[3], 1e-5), pos, 100.0)
+    v = t[2]
+    d = [x.to(dev) for x in (A, W, bias, *nw, cos16, sin16)]
+    outs = [torch.empty(H, M, 64, device=dev, dtype=torch.int16) for _ in range(3)]
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_gemm_qkv(BF16, _p(d[0]), _p(d[1]), _p(d[2]), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(d[3]), _p(d[4]),
+                                 _p(d[5]), _p(d[6]), _p(d[7]), _p(d[8]), M, H, K, P, psi, gw, 0.25, s) == 0
+    torch.cuda.synchronize()
+    for got, ref, nm in zip(outs, (q, k, v), "qkv"):
+        e = _rel(_from16(got, BF16).cpu(), ref[0])
+        print("gemm_qkv", nm, f"{e:.2e}")
+        assert e < 4e-3, nm   # one bf16 output rounding
+    # without norm / rope (the DINO blocks)
+    assert _lib().wm_op_gemm_qkv(BF16, _p(d[0]), _p(d[1]), _p(d[2]), _p(outs[0]), _p(outs[1]), _p(outs[2]), None, None, None, None,
+                                 None, None, M, H, K, P, 0, gw, 0.25, s) == 0
+    torch.cuda.synchronize()
+    for got, ref in zip(outs, (t[0] * 0.25, t[1], t[2])):
+        assert _rel(_from16(got, BF16).cpu(), ref[0]) < 4e-3
+
+
 def _conv_ref(x, w, b, stride, pad, relu_in, resid, resid_relu, resid2, dt):
     xin = torch.relu(x) if relu_in else x
     xin = _t16(xin, dt).float()
