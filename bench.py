@@ -157,10 +157,17 @@ def main():
     if rank == 0:
         dom = max(classes, key=lambda k: classes[k]["ms_total"])
         ach = classes[dom]["tflops"]
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # value is the committed rocprofv3 --pmc measurement of THIS workload (profiles/r01_traffic_n1.json), else null
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_n1.json")
+        if world == 1 and n_local == 8 and H == 518 and not a.tiny and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": classes[dom]["avg_ms"], "flops_per_launch": fl[dom] / classes[dom]["launches"],
                 "classes": classes, "forward_ms_events": round(whole_ms, 3),
+                "per_gpu_algorithmic_tflop": round(fl["total"] / 1e12, 2),
                 "whole_forward_tflops": round(fl["total"] / (ms_step * 1e-3) / 1e12, 1),
                 "whole_forward_frac": round(fl["total"] / (ms_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}
         line = {"metric": "views/sec", "value": round(n_total / (ms_step * 1e-3), 3), "unit": "views/s", "n_gpus": world,
