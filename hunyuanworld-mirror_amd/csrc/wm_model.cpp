@@ -80,6 +80,9 @@ struct wm_handle {
   int plan_n = -1, plan_nt = -1, plan_H = -1, plan_W = -1;
   // shape-dependent device tables (allocated inside the arena by plan())
   std::map<std::string, void*> buf;
+  // the DPT heads are mutually independent: each runs on its own stream (forked/joined with events)
+  hipStream_t hstream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t hfork = nullptr, hjoin[4] = {nullptr, nullptr, nullptr, nullptr};
   // profiling
   bool prof = false;
   std::vector<EvPair> ev[5];
@@ -293,21 +296,26 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   const int32_t* oc = c.dpt_out_channels;
   const size_t ch = d.chunk, hw = d.hw;
   const int Fm = std::max(c.dpt_features, c.enable_gs ? c.gs_dim : 0);
-  add("dpt_T16", ch * hw * D2 * 2);
-  add("dpt_P16", ch * hw * std::max(oc[0], oc[1]) * 2);
-  add("dpt_f0", ch * 16 * hw * oc[0] * 4);
-  add("dpt_f1", ch * 4 * hw * oc[1] * 4);
-  add("dpt_f2", ch * hw * oc[2] * 4);
-  add("dpt_f3in", ch * hw * oc[3] * 4);
-  add("dpt_f3", ch * (size_t)d.gh2 * d.gw2 * oc[3] * 4);
-  add("dpt_rn1", ch * 16 * hw * Fm * 4);
-  add("dpt_rn2", ch * 4 * hw * Fm * 4);
-  add("dpt_rn3", ch * hw * Fm * 4);
-  add("dpt_rn4", ch * (size_t)d.gh2 * d.gw2 * Fm * 4);
+  const int nslots = (c.enable_depth ? 1 : 0) + (c.enable_pts ? 1 : 0) + (c.enable_norm ? 1 : 0) + (c.enable_gs ? 1 : 0);
   const size_t big = ch * std::max<size_t>({64 * hw * (size_t)Fm, (size_t)d.H * d.W * (Fm / 2), (size_t)d.H * d.W * 32,
                                             c.enable_gs ? (size_t)d.H * d.W * c.gs_dim : 0}) * 4;
+  for (int sl = 0; sl < std::max(nslots, 1); ++sl) {
+    const std::string x = "_h" + std::to_string(sl);
+    auto addh = [&](const char* n, size_t b) { add((std::string(n) + x).c_str(), b); };
+    addh("dpt_T16", ch * hw * D2 * 2);
+    addh("dpt_P16", ch * hw * std::max(oc[0], oc[1]) * 2);
+    addh("dpt_f0", ch * 16 * hw * oc[0] * 4);
+    addh("dpt_f1", ch * 4 * hw * oc[1] * 4);
+    addh("dpt_f2", ch * hw * oc[2] * 4);
+    addh("dpt_f3in", ch * hw * oc[3] * 4);
+    addh("dpt_f3", ch * (size_t)d.gh2 * d.gw2 * oc[3] * 4);
+    addh("dpt_rn1", ch * 16 * hw * Fm * 4);
+    addh("dpt_rn2", ch * 4 * hw * Fm * 4);
+    addh("dpt_rn3", ch * hw * Fm * 4);
+    addh("dpt_rn4", ch * (size_t)d.gh2 * d.gw2 * Fm * 4);
+    for (int i = 0; i < 4; ++i) addh(("dpt_s" + std::to_string(i)).c_str(), big);
+  }
   if (c.enable_gs) add("gs_im2col", ch * (size_t)d.H * d.W * 192 * 2);
-  for (int i = 0; i < 4; ++i) add(("dpt_s" + std::to_string(i)).c_str(), big);
   for (int i = 0; i < 4; ++i) add(("dpt_pos" + std::to_string(i)).c_str(), hw * oc[i] * 4);
   add("dpt_posx", (size_t)d.W * (Fm / 4) * 4 * 2);  // one table per feature width (F/2 channels -> F/4 per axis)
   add("dpt_posy", (size_t)d.H * (Fm / 4) * 4 * 2);
@@ -434,6 +442,11 @@ extern "C" void wm_destroy(wm_handle* h) {
     if (kv.second.w16) (void)hipFree(kv.second.w16);
   }
   if (h->arena) (void)hipFree(h->arena);
+  for (int i = 0; i < 4; ++i) {
+    if (h->hstream[i]) (void)hipStreamDestroy(h->hstream[i]);
+    if (h->hjoin[i]) (void)hipEventDestroy(h->hjoin[i]);
+  }
+  if (h->hfork) (void)hipEventDestroy(h->hfork);
   for (int k = 0; k < 5; ++k)
     for (auto& e : h->ev[k]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (h->comm.kind == 1 && h->comm.nccl) ncclCommDestroy(h->comm.nccl);
@@ -836,21 +849,23 @@ wm_status rcu(Ctx& c, const std::string& p, const float* x, const float* extra, 
 
 // DPTHead (dense_head.py:107-295) for views [v0, v0+n) of this rank
 wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, bool is_gs, float* out_attr, float* out_conf,
-                   const float* img, const wm_outputs* out, int first_view) {
+                   const float* img, const wm_outputs* out, int first_view, int slot) {
+  const std::string sx = "_h" + std::to_string(slot);
+  auto HB = [&](const char* n) { return (float*)c.h->buf.at(std::string(n) + sx); };
   wm_handle* h = c.h;
   const Dims& d = c.d;
   const wm_config& cf = h->cfg;
   const int D2 = 2 * d.D, hw = d.hw, gh = d.gh, gw = d.gw;
   const int32_t* oc = cf.dpt_out_channels;
   const std::string sc = p + "scratch.";
-  float* S0 = B<float>(h, "dpt_s0"); float* S1 = B<float>(h, "dpt_s1"); float* S2 = B<float>(h, "dpt_s2"); float* S3 = B<float>(h, "dpt_s3");
+  float* S0 = HB("dpt_s0"); float* S1 = HB("dpt_s1"); float* S2 = HB("dpt_s2"); float* S3 = HB("dpt_s3");
   wm_status st;
   for (int v0 = 0; v0 < d.n; v0 += d.chunk) {
     const int n = std::min(d.chunk, d.n - v0);
-    float* feats[4] = {B<float>(h, "dpt_f0"), B<float>(h, "dpt_f1"), B<float>(h, "dpt_f2"), B<float>(h, "dpt_f3")};
+    float* feats[4] = {HB("dpt_f0"), HB("dpt_f1"), HB("dpt_f2"), HB("dpt_f3")};
     for (int i = 0; i < 4; ++i) {
       const float* tap = B<float>(h, ("tap" + std::to_string(i)).c_str()) + (size_t)v0 * d.P * D2;
-      void* T16 = B<void>(h, "dpt_T16");
+      void* T16 = HB("dpt_T16");
       st = layernorm(c, tap, D2, T16, D2, F(h, p + "norm.weight"), F(h, p + "norm.bias"), D2, 1e-5f, n, hw, d.P, d.psi, hw, 0, 0, c.hdt);
       if (st) return st;
       const std::string pj = p + "projects." + std::to_string(i);
@@ -859,7 +874,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       ex.rows_per_group = hw; ex.out_group = hw; ex.out_off = 0; ex.add = B<float>(h, ("dpt_pos" + std::to_string(i)).c_str());
       if (i < 2) {  // feeds a k==stride ConvTranspose (GEMM): 16-bit output
         ex.out16 = 1;
-        void* P16 = B<void>(h, "dpt_P16");
+        void* P16 = HB("dpt_P16");
         st = gemm(c, c.hdt, WM_EPI_ROWMAP_ADD, T16, D2, W16(h, pj + ".weight"), D2, P16, oc[i], F(h, pj + ".bias"), nullptr, n * hw, oc[i], D2, &ex);
         if (st) return st;
         const int k = i == 0 ? 4 : 2;
@@ -870,7 +885,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
         st = gemm(c, c.hdt, WM_EPI_CONVT, P16, oc[i], W16(h, rs + ".weight"), oc[i], feats[i], 0, F(h, rs + ".bias"), nullptr, n * hw, k * k * oc[i], oc[i], &ct);
         if (st) return st;
       } else {
-        float* dst = i == 2 ? feats[2] : B<float>(h, "dpt_f3in");
+        float* dst = i == 2 ? feats[2] : HB("dpt_f3in");
         st = gemm(c, c.hdt, WM_EPI_ROWMAP_ADD, T16, D2, W16(h, pj + ".weight"), D2, dst, oc[i], F(h, pj + ".bias"), nullptr, n * hw, oc[i], D2, &ex);
         if (st) return st;
         if (i == 3) {
@@ -880,7 +895,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       }
     }
     const int Hs[4] = {4 * gh, 2 * gh, gh, d.gh2}, Ws[4] = {4 * gw, 2 * gw, gw, d.gw2};
-    float* rn[4] = {B<float>(h, "dpt_rn1"), B<float>(h, "dpt_rn2"), B<float>(h, "dpt_rn3"), B<float>(h, "dpt_rn4")};
+    float* rn[4] = {HB("dpt_rn1"), HB("dpt_rn2"), HB("dpt_rn3"), HB("dpt_rn4")};
     for (int i = 0; i < 4; ++i) {
       st = conv(c, feats[i], sc + "layer" + std::to_string(i + 1) + "_rn", false, nullptr, false, nullptr, rn[i], n, Hs[i], Ws[i], 3, 1, 1, false);
       if (st) return st;
@@ -1054,25 +1069,40 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
     if (out->camera_poses && out->camera_intrs)
       LCHK(c, wm_launch_cam_matrices(B<float>(h, "cam_params"), out->camera_poses, out->camera_intrs, nt, H, W_, s));
   }
-  // ---- a13: DPT heads (worldmirror.py:74-98)
-  if (cf.enable_depth && out->depth && out->depth_conf) {
-    st = dpt_head(c, "depth_head.", cf.dpt_features, 2, WM_ACT_EXP, false, out->depth, out->depth_conf, img, out, first_view);
-    if (st) return st;
-  }
-  if (cf.enable_pts && out->pts3d && out->pts3d_conf) {
-    st = dpt_head(c, "pts_head.", cf.dpt_features, 4, WM_ACT_INV_LOG, false, out->pts3d, out->pts3d_conf, img, out, first_view);
-    if (st) return st;
-  }
-  if (cf.enable_norm && out->normals && out->normals_conf) {
-    st = dpt_head(c, "norm_head.", cf.dpt_features, 4, WM_ACT_NORM, false, out->normals, out->normals_conf, img, out, first_view);
-    if (st) return st;
-  }
-  if (cf.enable_gs && out->gs_depth && out->gs_depth_conf) {
-    if (out->splat_means && !(out->splat_quats && out->splat_scales && out->splat_opacities && out->splat_sh && out->splat_weights))
-      return fail(h, WM_ERR_INVALID, "splat outputs must be given together");
-    if (out->splat_means && !(cf.enable_cam && out->camera_params)) return fail(h, WM_ERR_INVALID, "splats need the camera head");
-    st = dpt_head(c, "gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf, img, out, first_view);
-    if (st) return st;
+  // ---- a13: DPT heads (worldmirror.py:74-98).  They are independent of each other and CAN run one per stream
+  // (WM_HEADS_CONCURRENT=1), but that is OFF: with several queues active, kernels of a dependent chain were
+  // measured to read stale 128-B lines of buffers rewritten earlier in the same stream (cross-XCD L2, see
+  // DESIGN.md "Multi-stream finding"); the single-stream path is bit-exact run to run.
+  {
+    struct HeadJob { const char* p; int F; int od; int act; bool gs; float* attr; float* conf; };
+    std::vector<HeadJob> jobs;
+    if (cf.enable_depth && out->depth && out->depth_conf) jobs.push_back({"depth_head.", cf.dpt_features, 2, WM_ACT_EXP, false, out->depth, out->depth_conf});
+    if (cf.enable_pts && out->pts3d && out->pts3d_conf) jobs.push_back({"pts_head.", cf.dpt_features, 4, WM_ACT_INV_LOG, false, out->pts3d, out->pts3d_conf});
+    if (cf.enable_norm && out->normals && out->normals_conf) jobs.push_back({"norm_head.", cf.dpt_features, 4, WM_ACT_NORM, false, out->normals, out->normals_conf});
+    if (cf.enable_gs && out->gs_depth && out->gs_depth_conf) {
+      if (out->splat_means && !(out->splat_quats && out->splat_scales && out->splat_opacities && out->splat_sh && out->splat_weights))
+        return fail(h, WM_ERR_INVALID, "splat outputs must be given together");
+      if (out->splat_means && !(cf.enable_cam && out->camera_params)) return fail(h, WM_ERR_INVALID, "splats need the camera head");
+      jobs.push_back({"gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf});
+    }
+    static const bool serial = getenv("WM_HEADS_CONCURRENT") == nullptr;
+    if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
+    if (!serial && jobs.size() > 1) LCHK(c, hipEventRecord(h->hfork, s));
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      Ctx hc = c;
+      if (!serial && jobs.size() > 1) {
+        if (!h->hstream[k]) LCHK(c, hipStreamCreateWithFlags(&h->hstream[k], hipStreamNonBlocking));
+        if (!h->hjoin[k]) LCHK(c, hipEventCreateWithFlags(&h->hjoin[k], hipEventDisableTiming));
+        hc.s = h->hstream[k];
+        LCHK(c, hipStreamWaitEvent(hc.s, h->hfork, 0));
+      }
+      st = dpt_head(hc, jobs[k].p, jobs[k].F, jobs[k].od, jobs[k].act, jobs[k].gs, jobs[k].attr, jobs[k].conf, img, out, first_view, (int)k);
+      if (st) return st;
+      if (hc.s != s) {
+        LCHK(c, hipEventRecord(h->hjoin[k], hc.s));
+        LCHK(c, hipStreamWaitEvent(s, h->hjoin[k], 0));
+      }
+    }
   }
   return WM_OK;
 }
