@@ -21,10 +21,23 @@
 
 namespace {
 
-constexpr int BK = 64;
+constexpr int BK = 64;  // default K-tile; the 32x32 kernel is also instantiated with BK = 32 (KT template parameter)
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
+
+// K-tile 32: rows are 64 B, a 1-KiB piece is 16 rows x 4 chunks; slot swizzle (row>>2)&3 keeps ds_read_b128 conflict-free
+__device__ __forceinline__ void stage_piece32(const u16* __restrict__ g, int ld, int row0, int nrows, int k0, char* lds_tile,
+                                              int piece, int lane) {
+  const int r = piece * 16 + (lane >> 2);
+  const int c = (lane & 3) ^ ((r >> 2) & 3);
+  int gr = row0 + r;
+  gr = gr < nrows ? gr : nrows - 1;
+  __builtin_amdgcn_global_load_lds((glb_vp)(g + (size_t)gr * ld + k0 + c * 8), (lds_vp)(lds_tile + piece * 1024), 16, 0, 0);
+}
+__device__ __forceinline__ s16x8 lds_frag32(const char* tile, int row, int chunk) {
+  return *(const s16x8*)(tile + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+}
 
 // one 1-KiB LDS-DMA piece = 8 rows x 128 B of an operand tile
 __device__ __forceinline__ void stage_piece(const u16* __restrict__ g, int ld, int row0, int nrows, int k0, char* lds_tile,
@@ -42,11 +55,12 @@ __device__ __forceinline__ s16x8 lds_frag(const char* tile, int row, int chunk) 
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE, int ILV>
+template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE, int ILV, int KT = 64>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs p) {
+  constexpr int BK = KT;
   constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int PA = BM / 8, PB = BN / 8;       // 1-KiB pieces per operand tile
+  constexpr int PA = BM * BK * 2 / 1024, PB = BN * BK * 2 / 1024;  // 1-KiB pieces per operand tile
   constexpr int PPW = (PA + PB) / NW;           // pieces per wave per K-tile
   static_assert((PA + PB) % NW == 0, "pieces must divide over waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,8 +78,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
       const int pc = wave * PPW + i;  // wave-uniform
-      if (pc < PA) stage_piece(A, p.lda, m0, p.M, kt * BK, base, pc, lane);
-      else stage_piece(W, p.ldw, n0, p.N, kt * BK, base + A_BYTES, pc - PA, lane);
+      if constexpr (BK == 64) {
+        if (pc < PA) stage_piece(A, p.lda, m0, p.M, kt * BK, base, pc, lane);
+        else stage_piece(W, p.ldw, n0, p.N, kt * BK, base + A_BYTES, pc - PA, lane);
+      } else {
+        if (pc < PA) stage_piece32(A, p.lda, m0, p.M, kt * BK, base, pc, lane);
+        else stage_piece32(W, p.ldw, n0, p.N, kt * BK, base + A_BYTES, pc - PA, lane);
+      }
     }
   };
   auto stage = [&](int kt, int s) { stage_part(kt, s, 0, PPW); };
@@ -86,7 +105,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
   for (int t = 0; t < nk; ++t) {
     // tile t must have landed; tiles t+1 .. t+NSTAGE-2 may stay in flight
     const int ahead = min(nk - 1 - t, NSTAGE - 2);
-    if (ahead >= 2) wait_vmcnt<2 * PPW>();
+    if (ahead >= 3) wait_vmcnt<3 * PPW>();
+    else if (ahead >= 2) wait_vmcnt<2 * PPW>();
     else if (ahead == 1) wait_vmcnt<PPW>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // everyone's pieces of tile t landed; everyone finished tile t-1
@@ -95,7 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
     const char* tA = smem + (t % NSTAGE) * STAGE;
     const char* tB = tA + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       if (ILV && more) {  // spread the LDS-DMA issue over the four MFMA groups of this K-tile
         constexpr int Q = (PPW + 3) / 4;
         stage_part(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE, ks * Q < PPW ? ks * Q : PPW, (ks + 1) * Q < PPW ? (ks + 1) * Q : PPW);
@@ -103,9 +123,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
       const int ch = 2 * ks + (lane >> 5);
       s16x8 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = lds_frag(tA, (wm * TM + i) * 32 + (lane & 31), ch);
+      for (int i = 0; i < TM; ++i)
+        a[i] = BK == 64 ? lds_frag(tA, (wm * TM + i) * 32 + (lane & 31), ch) : lds_frag32(tA, (wm * TM + i) * 32 + (lane & 31), ch);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = lds_frag(tB, (wn * TN + j) * 32 + (lane & 31), ch);
+      for (int j = 0; j < TN; ++j)
+        b[j] = BK == 64 ? lds_frag(tB, (wn * TN + j) * 32 + (lane & 31), ch) : lds_frag32(tB, (wn * TN + j) * 32 + (lane & 31), ch);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -313,18 +335,209 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
   }
 }
 
-template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE, int ILV>
+template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE, int ILV, int KT = 64>
 hipError_t launch_cfg(const WmGemmArgs& a, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t shm = (size_t)NSTAGE * (BM + BN) * KT * 2;
+  const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, TN, NSTAGE, ILV, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, TN, NSTAGE, ILV, KT>), dim3(ntm * ntn), dim3(WM * WN * 64), shm, s, a);
+  return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Same tile / staging / pipeline, but the inner product runs on v_mfma_f32_16x16x32 (guides "DVFS give-back"
+// item 7: at equal cycles per FLOP the chip holds a higher clock on this shape).  Backbone epilogues only.
+// Operands swapped as above: D[n = 4(lane>>4) + r][m = lane & 15] -> a lane owns row m and 4 consecutive columns.
+template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt16_kernel(const WmGemmArgs p) {
+  constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int SM = TM * 2, SN = TN * 2;  // 16-wide sub-tiles per wave
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 8, PB = BN / 8, PPW = (PA + PB) / NW;
+  static_assert((PA + PB) % NW == 0, "pieces must divide over waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+  const u16* A = (const u16*)p.A;
+  const u16* W = (const u16*)p.W;
+  auto stage = [&](int kt, int s) {
+    char* base = smem + s * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      if (pc < PA) stage_piece(A, p.lda, m0, p.M, kt * BK, base, pc, lane);
+      else stage_piece(W, p.ldw, n0, p.N, kt * BK, base + A_BYTES, pc - PA, lane);
+    }
+  };
+  f32x4 acc[SM][SN];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int j = 0; j < SN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+  const int l15 = lane & 15, lq = lane >> 4;
+  for (int t = 0; t < nk; ++t) {
+    const int ahead = min(nk - 1 - t, NSTAGE - 2);
+    if (ahead >= 2) wait_vmcnt<2 * PPW>();
+    else if (ahead == 1) wait_vmcnt<PPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
+    const char* tA = smem + (t % NSTAGE) * STAGE;
+    const char* tB = tA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = 4 * ks + lq;
+      s16x8 a[SM], b[SN];
+#pragma unroll
+      for (int i = 0; i < SM; ++i) a[i] = lds_frag(tA, wm * TM * 32 + i * 16 + l15, ch);
+#pragma unroll
+      for (int j = 0; j < SN; ++j) b[j] = lds_frag(tB, wn * TN * 32 + j * 16 + l15, ch);
+#pragma unroll
+      for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j) acc[i][j] = mfma16<T>(b[j], a[i], acc[i][j]);
+    }
+  }
+  // ---------------- epilogue ----------------
+  if constexpr (EPI == WM_EPI_QKV) {
+    static_assert(EPI != WM_EPI_QKV || TN == 2, "QKV epilogue needs 64 columns per wave");
+    const WmQkvArgs& q = p.qkv;
+    const int D = q.H * 64;
+    const int col0 = n0 + wn * 64;
+    const int which = col0 / D, head = (col0 - which * D) >> 6;
+    if (col0 >= p.N) return;
+    const float* nw = which == 0 ? q.qn_w : q.kn_w;
+    const float* nb = which == 0 ? q.qn_b : q.kn_b;
+    const bool do_norm = which < 2 && nw != nullptr, do_rope = which < 2 && q.rope_cos != nullptr;
+    u16* dst = (u16*)(which == 0 ? q.q : which == 1 ? q.k : q.v);
+    const float sc = which == 0 ? q.q_scale : 1.0f;
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      const int row = m0 + wm * TM * 32 + i * 16 + l15;
+      const bool row_ok = row < p.M;
+      float v[4][4];  // [j: 16-col group][e]: column 16j + 4*lq + e of this head
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bs = p.bias ? *(const float4*)(p.bias + col0 + 16 * j + 4 * lq) : make_float4(0, 0, 0, 0);
+        v[j][0] = acc[i][j][0] + bs.x; v[j][1] = acc[i][j][1] + bs.y; v[j][2] = acc[i][j][2] + bs.z; v[j][3] = acc[i][j][3] + bs.w;
+      }
+      if (do_norm) {  // the row's 64 values live in the 4 lanes l15 + 16*{0..3}
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm += v[j][e];
+        sm += __shfl_xor(sm, 16);
+        const float mean = xhalf_sum(sm) * (1.0f / 64.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[j][e] -= mean; ss += v[j][e] * v[j][e]; }
+        ss += __shfl_xor(ss, 16);
+        const float rstd = 1.0f / sqrtf(xhalf_sum(ss) * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 w4 = *(const float4*)(nw + 16 * j + 4 * lq), b4 = *(const float4*)(nb + 16 * j + 4 * lq);
+          v[j][0] = v[j][0] * rstd * w4.x + b4.x; v[j][1] = v[j][1] * rstd * w4.y + b4.y;
+          v[j][2] = v[j][2] * rstd * w4.z + b4.z; v[j][3] = v[j][3] * rstd * w4.w + b4.w;
+        }
+      }
+      if (do_rope) {
+        const int rr = row_ok ? row : 0;
+        const int t = rr % q.tokens_per_view;
+        int py = 0, px = 0;
+        if (t >= q.patch_start) {
+          const int idx = t - q.patch_start;
+          py = idx / q.grid_w + 1;
+          px = idx - (py - 1) * q.grid_w + 1;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {  // columns [0,32) rotate by y, [32,64) by x; pair (c, c+16) = groups (2hh, 2hh+1)
+          const int pos = hh == 0 ? py : px;
+          const float4 cs = *(const float4*)(q.rope_cos + pos * 16 + 4 * lq);
+          const float4 sn = *(const float4*)(q.rope_sin + pos * 16 + 4 * lq);
+          const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = v[2 * hh][e], hi = v[2 * hh + 1][e];
+            v[2 * hh][e] = lo * c4[e] - hi * s4[e];
+            v[2 * hh + 1][e] = hi * c4[e] + lo * s4[e];
+          }
+        }
+      }
+      if (row_ok) {
+        u16* o = dst + ((size_t)head * q.head_stride + row) * 64 + 4 * lq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint2 u;
+          u.x = (uint32_t)f2t<T>(v[j][0] * sc) | ((uint32_t)f2t<T>(v[j][1] * sc) << 16);
+          u.y = (uint32_t)f2t<T>(v[j][2] * sc) | ((uint32_t)f2t<T>(v[j][3] * sc) << 16);
+          *(uint2*)(o + 16 * j) = u;
+        }
+      }
+    }
+    return;
+  } else {
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      const int row = m0 + wm * TM * 32 + i * 16 + l15;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < SN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 16 + 4 * lq;
+        if (col >= p.N) continue;
+        const float4 bs = p.bias ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
+        float4 x = make_float4(acc[i][j][0] + bs.x, acc[i][j][1] + bs.y, acc[i][j][2] + bs.z, acc[i][j][3] + bs.w);
+        const size_t o = (size_t)row * p.ldc + col;
+        if constexpr (EPI == WM_EPI_F32) {
+          *(float4*)((float*)p.C + o) = x;
+        } else if constexpr (EPI == WM_EPI_T16 || EPI == WM_EPI_GELU_T16) {
+          if constexpr (EPI == WM_EPI_GELU_T16) x = make_float4(gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w));
+          uint2 u;
+          u.x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
+          u.y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
+          *(uint2*)((u16*)p.C + o) = u;
+        } else if constexpr (EPI == WM_EPI_RESID) {
+          const float4 old = *(const float4*)((const float*)p.C + o);
+          const float4 gm = *(const float4*)(p.gamma + col);
+          *(float4*)((float*)p.C + o) = make_float4(old.x + gm.x * x.x, old.y + gm.y * x.y, old.z + gm.z * x.z, old.w + gm.w * x.w);
+        }
+      }
+    }
+  }
+}
+
+template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE>
+hipError_t launch16_cfg(const WmGemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t shm = (size_t)NSTAGE * (BM + BN) * BK * 2;
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, TN, NSTAGE, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)gemm_nt16_kernel<T, EPI, WM, WN, TM, TN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, TN, NSTAGE, ILV>), dim3(ntm * ntn), dim3(WM * WN * 64), shm, s, a);
+  hipLaunchKernelGGL((gemm_nt16_kernel<T, EPI, WM, WN, TM, TN, NSTAGE>), dim3(ntm * ntn), dim3(WM * WN * 64), shm, s, a);
   return hipGetLastError();
+}
+
+template <int T, int EPI>
+hipError_t launch16_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
+  return cfg == 5 ? launch16_cfg<T, EPI, 2, 4, 3, 2, 2>(a, s) : launch16_cfg<T, EPI, 2, 4, 4, 2, 2>(a, s);
 }
 
 // tile configurations: id -> (WM, WN, TM, TN, NSTAGE)
@@ -340,12 +553,26 @@ hipError_t launch_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
     case 3: return launch_cfg<T, EPI, 2, 4, 4, 2, 2, 1>(a, s);
     case 4: return launch_cfg<T, EPI, 2, 4, 4, 2, 2, 0>(a, s);
     case 5: return launch_cfg<T, EPI, 2, 4, 3, 2, 2, 0>(a, s);
+    case 6: return launch_cfg<T, EPI, 2, 4, 4, 2, 4, 0, 32>(a, s);  // 256x256, K-tile 32, 4-stage ring (128 KiB)
     default: return hipErrorInvalidValue;
   }
 }
 
 template <int T>
 hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
+  // 16x16x32 MFMA main loop: measured +3..8 % on the N=1024 GEMMs (proj, fc2) and +0..2 % on QKV, neutral/negative
+  // on fc1 (tools/bench_gemm.py); WM_GEMM_MFMA16 = 0 / 2 forces it off / on for every backbone epilogue
+  static const int mf16 = [] { const char* e = getenv("WM_GEMM_MFMA16"); return e ? atoi(e) : 1; }();
+  if (mf16 && (cfg == 4 || cfg == 5)) {
+    switch (a.epi) {
+      case WM_EPI_F32: if (mf16 == 2) return launch16_E<T, WM_EPI_F32>(a, cfg, s); break;
+      case WM_EPI_T16: if (mf16 == 2) return launch16_E<T, WM_EPI_T16>(a, cfg, s); break;
+      case WM_EPI_GELU_T16: if (mf16 == 2) return launch16_E<T, WM_EPI_GELU_T16>(a, cfg, s); break;
+      case WM_EPI_RESID: return launch16_E<T, WM_EPI_RESID>(a, cfg, s);
+      case WM_EPI_QKV: return launch16_E<T, WM_EPI_QKV>(a, cfg, s);
+      default: break;
+    }
+  }
   switch (a.epi) {
     case WM_EPI_F32: return launch_E<T, WM_EPI_F32>(a, cfg, s);
     case WM_EPI_T16: return launch_E<T, WM_EPI_T16>(a, cfg, s);
@@ -382,7 +609,7 @@ int pick_cfg(const WmGemmArgs& a) {
 
 hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (a.K <= 0 || a.K % BK != 0 || a.N % 4 != 0) return hipErrorInvalidValue;
+  if (a.K <= 0 || a.K % 64 != 0 || a.N % 4 != 0) return hipErrorInvalidValue;
   if ((a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;  // 16-B aligned rows
   if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
   if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;

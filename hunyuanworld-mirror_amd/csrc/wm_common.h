@@ -38,7 +38,31 @@ __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// D(16x16 f32) += A(16x32) * B(32x16); lane l: A[row l&15][k=8(l>>4)+j], B[k=8(l>>4)+j][col l&15];
+// D: col = l&15, row = 4(l>>4) + r  (guides §3)
+template <int T>
+__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+  if constexpr (T == WM_T_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+// exact-erf GELU (nn.GELU() default, mlp.py:17).  erf via Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far
+// below the 16-bit output rounding) on v_rcp/v_exp: ~12 VALU ops instead of libm erff's ~40 — the GELU epilogue
+// was 26 % of the fc1 GEMM's wave time.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
