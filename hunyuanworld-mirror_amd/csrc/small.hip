@@ -7,6 +7,8 @@
 #include "wm_common.h"
 #include "wm_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
@@ -237,7 +239,18 @@ hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, 
 #define WM_STREAM(MT)                                                                                              \
   hipLaunchKernelGGL((linear_f32_stream_kernel<MT, 4>), dim3((N + 3) / 4, (M + MT - 1) / MT), dim3(256), 0, s, X, W, b, Y, \
                      M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate)
-    if (M <= 8) WM_STREAM(8);
+    static const int nc_force = [] { const char* e = getenv("WM_LIN_NC"); return e ? atoi(e) : 0; }();
+    const int nc = nc_force ? nc_force : 2;  // measured best (tools/bench_lin.py): ~2 TB/s
+    if (M <= 8 && nc == 8) {
+      hipLaunchKernelGGL((linear_f32_stream_kernel<8, 8>), dim3((N + 7) / 8, 1), dim3(256), 0, s, X, W, b, Y, M, N, K, ldx, ldy,
+                         pre_act, post_act, gamma, accumulate);
+    } else if (M <= 8 && nc == 2) {
+      hipLaunchKernelGGL((linear_f32_stream_kernel<8, 2>), dim3((N + 1) / 2, 1), dim3(256), 0, s, X, W, b, Y, M, N, K, ldx, ldy,
+                         pre_act, post_act, gamma, accumulate);
+    } else if (M <= 8 && nc == 1) {
+      hipLaunchKernelGGL((linear_f32_stream_kernel<8, 1>), dim3(N, 1), dim3(256), 0, s, X, W, b, Y, M, N, K, ldx, ldy,
+                         pre_act, post_act, gamma, accumulate);
+    } else if (M <= 8) WM_STREAM(8);
     else if (M <= 16) WM_STREAM(16);
     else WM_STREAM(32);
 #undef WM_STREAM
