@@ -21,6 +21,10 @@
 
 namespace {
 
+#ifndef WM_GEMM_PRIO
+#define WM_GEMM_PRIO 0
+#endif
+constexpr int PRIO = WM_GEMM_PRIO;
 constexpr int BK = 64;  // default K-tile; the 32x32 kernel is also instantiated with BK = 32 (KT template parameter)
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
     if (!ILV && more) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
     const char* tA = smem + (t % NSTAGE) * STAGE;
     const char* tB = tA + A_BYTES;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       if (ILV && more) {  // spread the LDS-DMA issue over the four MFMA groups of this K-tile
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(b[j], a[i], acc[i][j]);  // D[n][m]: lane = row m
       if (ILV) __builtin_amdgcn_sched_barrier(0);
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
   }
 
   // ---------------- epilogue: lane (m = lane&31, h = lane>>5), reg 4g+e <-> col 8g + 4h + e ----------------
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt16_kernel(const WmGemmArg
     if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, (t + NSTAGE - 1) % NSTAGE);
     const char* tA = smem + (t % NSTAGE) * STAGE;
     const char* tB = tA + A_BYTES;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = 4 * ks + lq;
@@ -410,6 +417,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt16_kernel(const WmGemmArg
 #pragma unroll
         for (int j = 0; j < SN; ++j) acc[i][j] = mfma16<T>(b[j], a[i], acc[i][j]);
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
   }
   // ---------------- epilogue ----------------
   if constexpr (EPI == WM_EPI_QKV) {

@@ -31,11 +31,61 @@ def _rng(name: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.Philox(key=[zlib.crc32(name.encode()), seed]))
 
 
-def make_param(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
-    """fp32 ndarray for one reference parameter name."""
+def _make_param_refinit(name: str, shape: Tuple[int, ...], n: np.ndarray) -> np.ndarray:
+    """Statistics of the reference's own initialisation.  DINOv2 encoder: Linear trunc_normal(0.02) with zero bias
+    (init_weights_vit_timm, vision_transformer.py:328-333), LayerScale 1.0 (visual_transformer.py:125), pos_embed
+    0.02, tokens 1e-6.  Everything else keeps torch's defaults: Linear / Conv weight AND bias ~ U(+-1/sqrt(fan_in))
+    (drawn here as a normal of the same variance 1/(3 fan_in)), LayerNorm 1/0, LayerScale 0.01 in the multi-view
+    blocks and the camera trunk (visual_transformer.py:65, camera_head.py:24), cam/reg tokens sigma 1e-6 (:247-248).
+    Only the fov bias is kept positive (random init gives fov = 0 -> focal = inf)."""
+    leaf = name.rsplit(".", 1)[-1]
+    dino = ".patch_embed." in name
+    if leaf == "pos_embed":
+        return (0.02 * np.clip(n, -2, 2)).astype(np.float32)
+    if leaf in _TOKENS:
+        return (1e-6 * n).astype(np.float32)
+    if leaf == "gamma":
+        return np.full(shape, 1.0 if dino else 0.01, np.float32)
+    is_norm = any(t in name for t in (".norm1.", ".norm2.", ".norm.", "q_norm.", "k_norm.", "token_norm.", "out_norm."))
+    if is_norm:
+        return np.ones(shape, np.float32) if leaf == "weight" else np.zeros(shape, np.float32)
+    if leaf == "bias":
+        if dino and "patch_embed.proj" not in name:
+            return np.zeros(shape, np.float32)
+        # fan_in is not recoverable from the bias shape alone: use the layer's known input widths by family
+        fan = _bias_fan_in(name, shape)
+        b = (n * np.float32(1.0 / np.sqrt(3.0 * fan))).astype(np.float32)
+        if name == "cam_head.param_predictor.fc2.bias":
+            b[7:9] = 0.3
+        return b
+    if dino and len(shape) == 2:
+        return (0.02 * np.clip(n, -2, 2)).astype(np.float32)
+    fan_in = shape[0] if ("resize_layers.0." in name or "resize_layers.1." in name) else int(np.prod(shape[1:]))
+    return (n * np.float32(1.0 / np.sqrt(3.0 * fan_in))).astype(np.float32)
+
+
+_FAN_CACHE: Dict[str, int] = {}
+
+
+def _bias_fan_in(name: str, shape) -> int:
+    """fan_in of the layer a bias belongs to (from the weight's shape in any spec that contains it)."""
+    if not _FAN_CACHE:
+        for cfg in (WMConfig(enable_gs=True), WMConfig.tiny(enable_gs=True)):
+            for k, sh in param_spec(cfg).items():
+                if k.endswith(".weight") and len(sh) >= 2:
+                    fan = sh[0] if ("resize_layers.0." in k or "resize_layers.1." in k) else int(np.prod(sh[1:]))
+                    _FAN_CACHE[k[:-7] + "|" + str(sh[0] if not ("resize_layers.0." in k or "resize_layers.1." in k) else sh[1])] = fan
+    return _FAN_CACHE.get(name[:-5] + "|" + str(shape[0]), 64)
+
+
+def make_param(name: str, shape: Tuple[int, ...], seed: int = 0, preset: str = "sensitive") -> np.ndarray:
+    """fp32 ndarray for one reference parameter name.  preset: "sensitive" (default, see module docstring)
+    or "refinit" (the reference's own init statistics)."""
     rng = _rng(name, seed)
     leaf = name.rsplit(".", 1)[-1]
     n = rng.standard_normal(shape, dtype=np.float32)
+    if preset == "refinit":
+        return _make_param_refinit(name, shape, n)
     if leaf in _TOKENS:
         return 0.2 * n
     if leaf == "gamma":
@@ -64,10 +114,10 @@ def make_param(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
     return w.astype(np.float32)
 
 
-def iter_params(cfg: WMConfig, seed: int = 0) -> Iterator[Tuple[str, np.ndarray]]:
+def iter_params(cfg: WMConfig, seed: int = 0, preset: str = "sensitive") -> Iterator[Tuple[str, np.ndarray]]:
     for name, shape in param_spec(cfg).items():
-        yield name, make_param(name, shape, seed)
+        yield name, make_param(name, shape, seed, preset)
 
 
-def make_state_dict(cfg: WMConfig, seed: int = 0) -> Dict[str, np.ndarray]:
-    return dict(iter_params(cfg, seed))
+def make_state_dict(cfg: WMConfig, seed: int = 0, preset: str = "sensitive") -> Dict[str, np.ndarray]:
+    return dict(iter_params(cfg, seed, preset))

@@ -189,12 +189,12 @@ class WorldMirror:
             self._upload()
         return missing, unexpected
 
-    def init_synthetic_weights(self, seed: int = 0):
+    def init_synthetic_weights(self, seed: int = 0, preset: str = "sensitive"):
         """Deterministic name-keyed weights (weights.py) — what parity tests and bench.py use."""
         if self._handle is not None:
-            self._upload(iter_params(self.cfg, seed))
+            self._upload(iter_params(self.cfg, seed, preset))
         else:
-            self._host_weights = dict(iter_params(self.cfg, seed))
+            self._host_weights = dict(iter_params(self.cfg, seed, preset))
         return self
 
     def _err(self) -> str:

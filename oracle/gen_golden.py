@@ -46,7 +46,7 @@ wm.VisualGeometryTransformer = _VGT
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def build_reference(cfg: WMConfig):
+def build_reference(cfg: WMConfig, preset: str = "sensitive"):
     """Reference model for ``cfg``; the full config uses the stock ctor, scaled-down configs swap
     scaled-down sub-modules into a stock shell (SURVEY §8c 'Scaled-down oracle')."""
     full = cfg.embed_dim == 1024 and cfg.depth == 24
@@ -88,7 +88,7 @@ def build_reference(cfg: WMConfig):
         [(k, ref_keys[k], spec[k]) for k in ref_keys if k in spec and ref_keys[k] != spec[k]][:10])
     with torch.no_grad():
         for k, v in sd.items():
-            v.copy_(torch.from_numpy(make_param(k, tuple(v.shape))))
+            v.copy_(torch.from_numpy(make_param(k, tuple(v.shape), 0, preset)))
     return m
 
 
@@ -121,12 +121,13 @@ def make_inputs(seed: int, S: int, H: int, W: int, priors: bool):
     return views
 
 
-def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True):
+def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="sensitive"):
     views_np = make_inputs(seed, S, H, W, priors=sum(flags) > 0)
     views = {k: torch.from_numpy(v.copy()) for k, v in views_np.items()}
     store = {f"in_{k}": v for k, v in views_np.items()}
     store["cond_flags"] = np.array(flags, np.int64)
     store["cfg_json"] = np.array(__import__("json").dumps(cfg.to_dict()))
+    store["weights_preset"] = np.array(preset)
     with torch.no_grad():
         if sum(flags) > 0:
             pri = m.extract_priors(views)
@@ -174,8 +175,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size 2x224 case (config C1)")
     ap.add_argument("--only-full", action="store_true")
+    ap.add_argument("--refinit", action="store_true", help="goldens with the reference's own init statistics")
     a = ap.parse_args()
     torch.manual_seed(0)
+    if a.refinit:
+        cfg = WMConfig.tiny()
+        m = build_reference(cfg, "refinit")
+        run_case(m, cfg, "refinit_tiny_3v_70x56_pose_ray", 21, 3, 70, 56, [1, 0, 1], preset="refinit")
+        cfg = WMConfig()
+        m = build_reference(cfg, "refinit")
+        run_case(m, cfg, "refinit_full_2v_224_noprior", 22, 2, 224, 224, [0, 0, 0], sub=4, keep_taps=False, preset="refinit")
+        return
     if not a.only_full:
         cfg = WMConfig.tiny()
         m = build_reference(cfg)

@@ -28,6 +28,10 @@ def load_golden(name):
     return cfg, views, [int(x) for x in z["cond_flags"]], outs, z
 
 
+def golden_preset(z):
+    return str(z["weights_preset"]) if "weights_preset" in z else "sensitive"
+
+
 def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
@@ -37,12 +41,12 @@ def rel_l2(a, b):
 _WCACHE = {}
 
 
-def torch_weights(cfg):
+def torch_weights(cfg, preset="sensitive"):
     """Synthetic name-keyed weights as torch fp32 tensors (cached per config)."""
     import torch
     from hunyuanworld_mirror_amd.weights import iter_params
-    key = json.dumps(cfg.to_dict(), sort_keys=True)
+    key = json.dumps(cfg.to_dict(), sort_keys=True) + preset
     if key not in _WCACHE:
         _WCACHE.clear()
-        _WCACHE[key] = {k: torch.from_numpy(v) for k, v in iter_params(cfg)}
+        _WCACHE[key] = {k: torch.from_numpy(v) for k, v in iter_params(cfg, 0, preset)}
     return _WCACHE[key]

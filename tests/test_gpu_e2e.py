@@ -106,6 +106,30 @@ def test_full_arch_2x224_golden():
         assert abs(s - ref) / abs(ref) < 2e-3, (k, s, ref)
 
 
+@pytest.mark.parametrize("name", ["refinit_tiny_3v_70x56_pose_ray", "refinit_full_2v_224_noprior"])
+def test_refinit_weights_bf16_meets_north_star(name):
+    """With the reference's own init statistics (weights.py preset "refinit": DINO trunc_normal 0.02 / LayerScale 1,
+    torch-default U(+-1/sqrt(fan_in)) elsewhere, LayerScale 0.01 in the multi-view blocks — what the SURVEY's
+    3.0e-4 emulation used) the bf16 recipe meets the north-star tolerance: pts3d / depth / normals rel-L2 < 1e-3
+    against the reference's fp32 CPU output.  Measured r01: full 2x224 pts3d 3.2e-4, depth 4.6e-5, normals 4.3e-4;
+    tiny pts3d 1.6e-4.  Camera parameters (cam token ~1e-6 + 0.01-scaled bf16 increments) are looser: < 2e-2."""
+    from conftest import golden_preset
+    cfg, views, flags, outs, z = load_golden(name)
+    from hunyuanworld_mirror_amd import WorldMirror
+    m = WorldMirror(arch=cfg).to("cuda:0").init_synthetic_weights(preset=golden_preset(z))
+    got = _run(m, views, flags)
+    sub = int(z["subsample"])
+    errs = {}
+    for k, v in outs.items():
+        g = got[k].cpu().numpy()
+        if sub > 1 and g.ndim >= 4 and g.shape[2] == views["img"].shape[-2]:
+            g = g[:, :, ::sub, ::sub]
+        errs[k] = rel_l2(g, v)
+    print(name, {k: f"{e:.2e}" for k, e in errs.items()})
+    assert errs["pts3d"] < 1e-3 and errs["depth"] < 1e-3 and errs["normals"] < 1e-3, errs
+    assert errs["camera_params"] < 2e-2 and errs["camera_poses"] < 2e-2, errs
+
+
 def test_tiny_gs_branch_golden():
     """BASELINE config 5 path (3D-Gaussian head, rasterisation stubbed): gs_depth, the per-pixel splats of
     prepare_splats (rasterization.py:389-498) and the voxel-pruned splats (:301-387) vs the reference."""

@@ -19,8 +19,9 @@ TOL = 1e-5
 
 
 def _run(name, **kw):
+    from conftest import golden_preset
     cfg, views, flags, outs, z = load_golden(name)
-    P = torch_weights(cfg)
+    P = torch_weights(cfg, golden_preset(z))
     col = {}
     with torch.no_grad():
         o = R.forward(P, {k: torch.from_numpy(v) for k, v in views.items()}, flags, cfg, collect=col, **kw)
@@ -34,6 +35,13 @@ def test_oracle_matches_reference_tiny(name):
         assert rel_l2(col["taps"][i].numpy(), z[f"tap{i}"]) < TOL, f"tap{i}"
     for k, v in outs.items():
         assert o[k].shape == v.shape, k
+        assert rel_l2(o[k].numpy(), v) < TOL, k
+
+
+def test_oracle_matches_reference_refinit_weights():
+    """Second weight preset (the reference's own init statistics): same restatement, same tolerance."""
+    cfg, o, outs, z, col = _run("refinit_tiny_3v_70x56_pose_ray")
+    for k, v in outs.items():
         assert rel_l2(o[k].numpy(), v) < TOL, k
 
 
