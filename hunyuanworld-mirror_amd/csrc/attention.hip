@@ -296,7 +296,8 @@ hipError_t launch(const WmAttnArgs& a, hipStream_t s) {
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (a.q_rows <= 0) return hipSuccess;
   if (a.seq_len <= 0 || a.q_rows % a.seq_len != 0 || a.kv_chunks < 1) return hipErrorInvalidValue;
-  static const int forced = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
+  static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
+  const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
   const int qb = forced ? forced : (a.seq_len < 4096 ? 4 : 3);  // 64 rows per wave at 2 waves/SIMD measured best on every shape
   if (qb == 2) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 1>(a, s) : launch<WM_T_F16, 4, 2, 1>(a, s);
   if (qb == 3) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s) : launch<WM_T_F16, 4, 2, 2>(a, s);

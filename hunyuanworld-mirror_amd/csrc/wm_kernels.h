@@ -118,3 +118,9 @@ hipError_t wm_launch_adaln(const float* tok, const float* mod, float* h, int S, 
 hipError_t wm_launch_cam_update(float* pred, const float* delta, float* out, int S, int first, hipStream_t s);
 // camera_params [S][9] -> c2w [S][16], K [S][9]  (camera_utils.py:46-75, worldmirror.py:165-175)
 hipError_t wm_launch_cam_matrices(const float* params, float* poses, float* intrs, int S, int H, int W, hipStream_t s);
+
+// Process-wide tuning overrides (wm_set_tuning in the C ABI; tests and A/B tools).  -1 = not set: the kernel's
+// launcher falls back to its environment variable, then to its built-in choice.
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_COUNT };
+extern int wm_tuning[WM_TUNE_COUNT];
+

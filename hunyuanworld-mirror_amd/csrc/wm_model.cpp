@@ -416,6 +416,13 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
     }
 }
 
+extern "C" int wm_set_tuning(const char* key, int value) {
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad"};
+  for (int i = 0; i < WM_TUNE_COUNT; ++i)
+    if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
+  return -1;
+}
+
 extern "C" void wm_host_to_16(const float* in, uint16_t* out, size_t n, int dtype) {
   for (size_t i = 0; i < n; ++i) out[i] = h_to16(in[i], dtype);
 }
@@ -1184,6 +1191,7 @@ extern "C" wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* W
   WmGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.W = Wp; a.C = C; a.bias = bias; a.gamma = gamma; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N;
+  if (wm_tuning[WM_TUNE_OP_LDPAD] > 0) a.lda = a.ldw = K + wm_tuning[WM_TUNE_OP_LDPAD];  // wm_op_gemm only: operand row pitch (elements)
   a.dtype = dtype; a.epi = epi;
   return wm_launch_gemm(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }

@@ -127,6 +127,11 @@ wm_status wm_op_bilinear(const float* in, float* out, int N, int Hi, int Wi, int
 wm_status wm_op_linear_f32(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int ldx, int pre_act,
                            int post_act, void* stream);
 /* host helper: fp32 -> 16-bit (round to nearest even), for building test operands */
+/* Process-wide kernel-selection override for tests and A/B tools (no reference counterpart).  key: "gemm_cfg"
+ * (tile config id), "gemm_pp" (0/1 ping-pong GEMM), "gemm_mfma16" (0/1/2), "attn_qb" (attention variant);
+ * value -1 restores the default.  Returns 0, or -1 for an unknown key. */
+int wm_set_tuning(const char* key, int value);
+
 void wm_host_to_16(const float* in, uint16_t* out, size_t n, int dtype);
 
 #ifdef __cplusplus

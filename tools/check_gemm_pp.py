@@ -1,0 +1,54 @@
+"""GPU: ping-pong GEMM (gemm_pp_kernel) vs fp32 torch on exact 16-bit operands, all backbone epilogues, ragged shapes,
+repeated launches (race screen), then an interleaved in-process A/B timing against the lock-step kernels."""
+import ctypes as C, sys, json, math
+import torch
+sys.path.insert(0, '.')
+from hunyuanworld_mirror_amd import _lib
+L = _lib.lib(); dev = torch.device('cuda:0')
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def tune(k, v): assert L.wm_set_tuning(k.encode(), v) == 0
+def rel(a, b): return float((a.double() - b.double()).norm() / b.double().norm())
+bad = 0
+for cfg, ppv in ((4, 1), (4, 3), (5, 1)):
+    tune("gemm_cfg", cfg); tune("gemm_pp", ppv)
+    for (M, N, K) in [(256, 256, 64), (192, 256, 128), (1000, 384, 640), (11008, 1024, 1024), (2752, 3072, 1024), (777, 4096, 1024), (5000, 1024, 4096), (300, 64, 192), (513, 256, 64), (2000, 512, 128)]:
+        g = torch.Generator().manual_seed(M + N + K)
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+        bias = torch.randn(N, generator=g).to(dev); gamma = torch.randn(N, generator=g).to(dev)
+        ref = A.float() @ W.float().t() + bias
+        worst = 0.0
+        for it in range(6):
+            out = torch.full((M, N), float('nan'), device=dev)
+            assert L.wm_op_gemm(0, 0, p(A), p(W), p(out), p(bias), None, M, N, K, s) == 0
+            e0 = rel(out, ref)
+            o16 = torch.zeros(M, N, device=dev, dtype=torch.int16)
+            assert L.wm_op_gemm(0, 2, p(A), p(W), p(o16), p(bias), None, M, N, K, s) == 0
+            e2 = rel(o16.view(torch.bfloat16).float(), torch.nn.functional.gelu(ref))
+            X0 = torch.randn(M, N, generator=g).to(dev); X = X0.clone()
+            assert L.wm_op_gemm(0, 3, p(A), p(W), p(X), p(bias), p(gamma), M, N, K, s) == 0
+            e3 = rel(X, X0 + gamma * ref)
+            worst = max(worst, e0, e3, e2 / 300)
+        ok = worst < 2e-5
+        bad += not ok
+        print(f"cfg{cfg} pp{ppv} {M}x{N}x{K}: f32 {e0:.1e} gelu16 {e2:.1e} resid {e3:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+print("FAILS", bad)
+# ---- A/B timing, interleaved in one process
+SH = [("qkv", 0, 3072, 1024), ("proj", 3, 1024, 1024), ("fc1", 2, 4096, 1024), ("fc2", 3, 1024, 4096)]
+for M in (11008, 44032):
+    for name, epi, N, K in SH:
+        A = torch.randn(M, K, device=dev).to(torch.bfloat16); W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev); gamma = torch.randn(N, device=dev)
+        Cc = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi in (0, 3) else torch.int16)
+        res = {}
+        for rep in range(2):
+            for label, cfg, pp in (("old4", 4, 0), ("old5", 5, 0), ("pp4v1", 4, 3), ("pp4v2", 4, 1), ("pp5", 5, 1)):
+                tune("gemm_cfg", cfg); tune("gemm_pp", pp)
+                for _ in range(2): L.wm_op_gemm(0, epi, p(A), p(W), p(Cc), p(bias), p(gamma), M, N, K, s)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): L.wm_op_gemm(0, epi, p(A), p(W), p(Cc), p(bias), p(gamma), M, N, K, s)
+                e1.record(); torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                res.setdefault(label, []).append(round(2 * M * N * K / ms / 1e9))
+        print(json.dumps({"M": M, "gemm": name, "tflops": res}), flush=True)
