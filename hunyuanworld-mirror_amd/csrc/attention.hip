@@ -53,7 +53,7 @@ __device__ __forceinline__ float ceil_t16(float x) {
   return y;
 }
 
-template <int T, int NW, int QB, int MINW>
+template <int T, int NW, int QB, int MINW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int QT = NW * 32 * QB;  // query rows per block; each wave owns QB blocks of 32 rows
@@ -65,7 +65,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
   const int nseq = p.q_rows / p.seq_len;
   const int tiles_per_head = tiles_per_seq * nseq;
-  const int lid = xcd_remap(blockIdx.x, tiles_per_head * p.H);
+  const int nsplit = p.kv_splits;
+  int lid = xcd_remap(blockIdx.x, tiles_per_head * p.H * nsplit);
+  const int split = lid % nsplit;
+  lid /= nsplit;
   const int head = lid / tiles_per_head;
   const int tile = lid - head * tiles_per_head;
   const int seq = tile / tiles_per_seq;
@@ -148,18 +151,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
       for (int r = 0; r < 16; ++r) ot[b][d][r] = 0.f;
   }
 
-  load_tile(0);
+  // this block's slice of the key tiles (every slice is non-empty: the launcher keeps kv_splits <= ntiles)
+  const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
+  load_tile(t0);
   store_tile(0);
   __syncthreads();
 
   // per-lane constant part of the transposed V read address (see header)
   const int vtr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
     const char* kt = smem + cur * 2 * TILE_B;
     const char* vt = kt + TILE_B;
-    if (t + 1 < ntiles) load_tile(t + 1);  // global -> regs, hidden under the MFMA phase
+    if (t + 1 < t1 && DBG != 3) load_tile(t + 1);  // global -> regs, hidden under the MFMA phase
 
     // ---- S^T = K Q^T : st[b][k2][r] = S[key = 32k2 + (r&3)+8(r>>2)+4h][q = ql of block b]
     f32x16 st[QB][2];
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
       for (int ks = 0; ks < 4; ++ks) {
         const s16x8 kf = *(const s16x8*)(kt + key * 128 + (((2 * ks + h) ^ ((key >> 1) & 7)) << 4));
 #pragma unroll
-        for (int b = 0; b < QB; ++b) st[b][k2] = mfma32<T>(kf, qf[b][ks], st[b][k2]);
+        for (int b = 0; b < QB; ++b)
+          if (DBG != 2 || ks == 0) st[b][k2] = mfma32<T>(kf, qf[b][ks], st[b][k2]);
       }
     }
     // ---- tail mask (wave-uniform branch; only the last tile of a segment)
@@ -197,13 +203,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
       float mloc = st[b][0][0];
+      if (DBG != 1) {
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[b][0][r]);
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[b][0][r]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[b][1][r]);
-      mloc = xhalf_max(mloc);  // max of S' = S - m_run over this tile (same value in both lane halves)
-      if (t == 0 || !__all(mloc <= 0.f)) {  // wave-uniform: some row's max grew (always on the first tile)
-        const float cand = m_run[b] + (t == 0 ? mloc : fmaxf(mloc, 0.f));
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[b][1][r]);
+        mloc = xhalf_max(mloc);
+      }  // max of S' = S - m_run over this tile (same value in both lane halves)
+      if (t == t0 || !__all(mloc <= 0.f)) {  // wave-uniform: some row's max grew (always on the first tile)
+        const float cand = m_run[b] + (t == t0 ? mloc : fmaxf(mloc, 0.f));
         const float m_new = ceil_t16<T>(cand);
         const float d2 = m_new - m_run[b];
         m_run[b] = m_new;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
           for (int r = 0; r < 16; ++r) st[b][k2][r] -= d2;
-        if (t > 0) {
+        if (t > t0) {
           const float alpha = __builtin_amdgcn_exp2f(-d2);
           l_run[b] *= alpha;
 #pragma unroll
@@ -226,8 +234,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
         float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pv[r] = __builtin_amdgcn_exp2f(st[b][k2][r]);
-          l_run[b] += pv[r];
+          pv[r] = DBG == 1 ? st[b][k2][r] : __builtin_amdgcn_exp2f(st[b][k2][r]);
+          if (DBG != 1) l_run[b] += pv[r];
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -255,11 +263,31 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
           vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
           vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
 #pragma unroll
-          for (int b = 0; b < QB; ++b) ot[b][d] = mfma32<T>(vf, pf[b][k2][s2], ot[b][d]);
+          for (int b = 0; b < QB; ++b)
+            if (DBG != 2 || (k2 == 0 && s2 == 0)) ot[b][d] = mfma32<T>(vf, pf[b][k2][s2], ot[b][d]);
         }
       }
-    if (t + 1 < ntiles) store_tile(cur ^ 1);
-    __syncthreads();
+    if (DBG != 3) {
+      if (t + 1 < t1) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  if (nsplit > 1) {  // unnormalised partial: O^T (fp32), running max and sum; the combine pass finishes the softmax
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      const float lsum = xhalf_sum(l_run[b]);
+      if (!q_valid[b]) continue;
+      const size_t row = (size_t)(seq_row0 + qrow[b]);
+      float* op = p.part_o + ((size_t)split * p.q_rows + row) * (p.H * 64) + head * 64;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(op + 32 * d + 8 * g + 4 * h) = make_float4(ot[b][d][4 * g], ot[b][d][4 * g + 1], ot[b][d][4 * g + 2], ot[b][d][4 * g + 3]);
+      if (h == 0) *(float2*)(p.part_ml + (((size_t)split * p.H + head) * p.q_rows + row) * 2) = make_float2(m_run[b], lsum);
+    }
+    return;
   }
 
   // ---- epilogue: O[q][head*64 + d] = O^T / l
@@ -281,13 +309,65 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   }
 }
 
-template <int T, int NW, int QB, int MINW>
-hipError_t launch(const WmAttnArgs& a, hipStream_t s) {
+// O[row][head*64 + d] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s ; one thread per (row, head, 4 channels)
+template <int T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int d4 = (int)(id & 15);
+  const size_t rh = id >> 4;
+  const int head = (int)(rh % p.H);
+  const size_t row = rh / p.H;
+  if (row >= (size_t)p.q_rows) return;
+  float m[WM_ATTN_MAX_SPLITS], l[WM_ATTN_MAX_SPLITS], M = -INFINITY;
+  for (int s = 0; s < p.kv_splits; ++s) {
+    const float2 ml = *(const float2*)(p.part_ml + (((size_t)s * p.H + head) * p.q_rows + row) * 2);
+    m[s] = ml.x; l[s] = ml.y;
+    M = fmaxf(M, ml.x);
+  }
+  float L = 0.f;
+  float4 o = make_float4(0, 0, 0, 0);
+  for (int s = 0; s < p.kv_splits; ++s) {
+    const float w = __builtin_amdgcn_exp2f(m[s] - M);
+    L += w * l[s];
+    const float4 v = *(const float4*)(p.part_o + ((size_t)s * p.q_rows + row) * (p.H * 64) + head * 64 + d4 * 4);
+    o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
+  }
+  const float inv = 1.0f / L;
+  uint2 u;
+  u.x = pack2(o.x * inv, o.y * inv, T);
+  u.y = pack2(o.z * inv, o.w * inv, T);
+  *(uint2*)((u16*)p.O + (row * p.H + head) * 64 + d4 * 4) = u;
+}
+
+template <int T, int NW, int QB, int MINW, int DBG = 0>
+hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
   constexpr int QT = NW * 32 * QB;
+  WmAttnArgs a = a_in;
   const int tiles_per_seq = (a.seq_len + QT - 1) / QT;
   const int nseq = a.q_rows / a.seq_len;
-  dim3 grid(tiles_per_seq * nseq * a.H), block(NW * 64);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW>), grid, block, 0, s, a);
+  {  // split-KV choice: rounds over the resident slots, per unit of work; a split must beat 1 by > 6 % (combine cost)
+    static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    const long slots = (long)ncu * MINW * 4 / NW, blocks = (long)tiles_per_seq * nseq * a.H;
+    const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
+    const int ntiles = (seg_rows + KVB - 1) / KVB * a.kv_chunks;
+    int lim = a.part_o && a.part_ml ? (a.max_splits > 0 ? a.max_splits : WM_ATTN_MAX_SPLITS) : 1;
+    lim = lim < WM_ATTN_MAX_SPLITS ? lim : WM_ATTN_MAX_SPLITS;
+    lim = lim < ntiles / 8 ? lim : (ntiles / 8 > 1 ? ntiles / 8 : 1);  // keep slices >= 8 tiles
+    int best = 1;
+    if (a.kv_splits > 0) best = a.kv_splits < lim ? a.kv_splits : lim;
+    else if (wm_tuning[WM_TUNE_ATTN_SPLITS] > 0) best = wm_tuning[WM_TUNE_ATTN_SPLITS] < lim ? wm_tuning[WM_TUNE_ATTN_SPLITS] : lim;
+    // no automatic split: measured (tools/bench_attn.py) 8-view cross-view attention is the same speed at 1-4 splits and
+    // the short per-frame sequences lose 15-20 % — a wave that is alone on its SIMD runs its tiles about twice as fast,
+    // so a partly filled last round costs nothing.  (blocks, slots kept for the tuning hook / future kernels.)
+    (void)blocks; (void)slots;
+    a.kv_splits = best;
+  }
+  dim3 grid(tiles_per_seq * nseq * a.H * a.kv_splits), block(NW * 64);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, DBG>), grid, block, 0, s, a);
+  if (a.kv_splits > 1) {
+    const size_t nthr = (size_t)a.q_rows * a.H * 16;
+    hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -299,6 +379,12 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
   const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
   const int qb = forced ? forced : (a.seq_len < 4096 ? 4 : 3);  // 64 rows per wave at 2 waves/SIMD measured best on every shape
+#ifdef WM_ATTN_DEBUG  // timing experiments only (wrong results): 11 no softmax VALU, 12 a quarter of the MFMAs, 13 no K/V streaming
+  if (qb == 11) return launch<WM_T_BF16, 4, 2, 2, 1>(a, s);
+  if (qb == 12) return launch<WM_T_BF16, 4, 2, 2, 2>(a, s);
+  if (qb == 13) return launch<WM_T_BF16, 4, 2, 2, 3>(a, s);
+  if (qb == 14) return launch<WM_T_BF16, 4, 2, 1, 0>(a, s);
+#endif
   if (qb == 2) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 1>(a, s) : launch<WM_T_F16, 4, 2, 1>(a, s);
   if (qb == 3) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s) : launch<WM_T_F16, 4, 2, 2>(a, s);
   if (qb == 4) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3>(a, s) : launch<WM_T_F16, 4, 1, 3>(a, s);

@@ -49,8 +49,14 @@ struct WmAttnArgs {
   long long kv_chunk_stride;  // elements between chunks
   int kv_rows_per_chunk;      // valid rows per head in each chunk (when kv_chunks > 1)
   int dtype;
+  // split-KV (fills the chip when q-tiles x heads does not): each of kv_splits blocks per q-tile walks a slice of
+  // the key tiles and writes an unnormalised partial; wm_launch_attention runs the combine pass itself.
+  // kv_splits 0 = choose (1 when no workspace is given); part_o: fp32 [kv_splits][q_rows][H*64]; part_ml: fp32 [kv_splits][H][q_rows][2]
+  int kv_splits, max_splits;
+  float* part_o; float* part_ml;
 };
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s);
+constexpr int WM_ATTN_MAX_SPLITS = 4;
 
 // ------------------------------------------------------------------ elementwise (elementwise.hip)
 // LayerNorm over the last dim with row remapping: out row (g*out_group + out_off + q) <- in row
@@ -121,6 +127,6 @@ hipError_t wm_launch_cam_matrices(const float* params, float* poses, float* intr
 
 // Process-wide tuning overrides (wm_set_tuning in the C ABI; tests and A/B tools).  -1 = not set: the kernel's
 // launcher falls back to its environment variable, then to its built-in choice.
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

@@ -269,6 +269,8 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("H16", Mx * 4 * D * 2);
   for (int i = 0; i < 4; ++i) add(("tap" + std::to_string(i)).c_str(), Mv * 2 * D * 4);
   add("KVG", (size_t)d.world * 2 * Mv * D * 2);
+  add("ATT_PO", (size_t)2 * Mx * D * 4);   // split-KV attention partials (2 splits): unnormalised O, (max, sum)
+  add("ATT_ML", (size_t)2 * Mx * (D / 64) * 2 * 4);
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("dino_pos", (size_t)(1 + d.hw) * D * 4);
@@ -417,7 +419,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -751,6 +753,7 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     } else {
       a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
     }
+    a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = 2;
     ProfScope ps(h, is_global ? 0 : 1, c.s);
     LCHK(c, wm_launch_attention(a, c.s));
   }
@@ -1213,6 +1216,19 @@ extern "C" wm_status wm_op_attention(int dtype, const void* Q, const void* K, co
   memset(&a, 0, sizeof(a));
   a.Q = Q; a.K = K; a.V = V; a.O = O; a.H = H; a.q_rows = q_rows; a.seq_len = seq_len; a.q_head_stride = q_rows;
   a.kv_chunks = kv_chunks; a.dtype = dtype;
+  if (kv_chunks > 1) {
+    a.kv_head_stride = kv_rows_per_chunk; a.kv_rows_per_chunk = kv_rows_per_chunk; a.kv_chunk_stride = (long long)H * kv_rows_per_chunk * 64;
+  } else {
+    a.kv_head_stride = q_rows;
+  }
+  return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_attention_split(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
+                                           int kv_chunks, int kv_rows_per_chunk, int kv_splits, float* part_o, float* part_ml, void* stream) {
+  WmAttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.H = H; a.q_rows = q_rows; a.seq_len = seq_len; a.q_head_stride = q_rows;
+  a.kv_chunks = kv_chunks; a.dtype = dtype; a.kv_splits = kv_splits; a.max_splits = WM_ATTN_MAX_SPLITS; a.part_o = part_o; a.part_ml = part_ml;
   if (kv_chunks > 1) {
     a.kv_head_stride = kv_rows_per_chunk; a.kv_rows_per_chunk = kv_rows_per_chunk; a.kv_chunk_stride = (long long)H * kv_rows_per_chunk * 64;
   } else {

@@ -115,6 +115,12 @@ wm_status wm_op_gemm_qkv(int dtype, const void* A, const void* W, const float* b
 /* Q must be pre-scaled by log2(e)/sqrt(64) (what wm_op_qkv_post does with q_scale): softmax is evaluated in base 2 */
 wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
                           int kv_chunks, int kv_rows_per_chunk, void* stream);
+/* Same with split-KV: kv_splits (1..4; 0 = choose) blocks per query tile each walk a slice of the keys and write
+ * unnormalised partials into part_o (fp32 [kv_splits][q_rows][H*64]) and part_ml (fp32 [kv_splits][H][q_rows][2]);
+ * a combine kernel finishes the softmax.  Used by the forward for cross-view attention when q-tiles x heads does
+ * not fill the chip. */
+wm_status wm_op_attention_split(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
+                                int kv_chunks, int kv_rows_per_chunk, int kv_splits, float* part_o, float* part_ml, void* stream);
 wm_status wm_op_layernorm(const float* x, void* y, const float* w, const float* b, int rows, int D, float eps, int out_f32,
                           int dtype, void* stream);
 wm_status wm_op_qkv_post(int dtype, const float* qkv, void* q, void* k, void* v, const float* qn_w, const float* qn_b,

@@ -176,6 +176,36 @@ def test_attention_kv_chunks_equals_concat(dev):
     assert _rel(_from16(o, BF16).reshape(Lq, H, 64), ref) < 8e-3
 
 
+@pytest.mark.parametrize("H,L,chunks,splits", [(4, 2752, 1, 2), (2, 2200, 1, 4), (3, 1100, 2, 2), (2, 5504, 1, 3)])
+def test_attention_split_kv(dev, H, L, chunks, splits):
+    """Split-KV (partials + combine pass) == the single-pass kernel == fp32 softmax; the spike key sits in the LAST
+    slice so the slices' running maxima differ by a lot (the combine must rescale, not just add)."""
+    g = torch.Generator().manual_seed(H * 31 + L + splits)
+    Lk = L // chunks if chunks > 1 else L
+    q = torch.randn(H, L, 64, generator=g) * 0.125 * LOG2E
+    k = torch.randn(chunks, H, Lk, 64, generator=g)
+    v = torch.randn(chunks, H, Lk, 64, generator=g)
+    k[-1, :, Lk - 5] = q[:, 33] * 8 * 30.0
+    q, k, v = [_t16(x, BF16).to(dev) for x in (q, k, v)]
+    o1 = torch.empty(L, H * 64, device=dev, dtype=torch.int16)
+    o2 = torch.zeros(L, H * 64, device=dev, dtype=torch.int16)
+    po = torch.full((splits, L, H * 64), float("nan"), device=dev)
+    pml = torch.full((splits, H, L, 2), float("nan"), device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L_ = _lib()
+    assert L_.wm_op_attention(BF16, _p(q), _p(k), _p(v), _p(o1), H, L, L, chunks, Lk if chunks > 1 else 0, s) == 0
+    assert L_.wm_op_attention_split(BF16, _p(q), _p(k), _p(v), _p(o2), H, L, L, chunks, Lk if chunks > 1 else 0, splits, _p(po), _p(pml), s) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(po).all() and torch.isfinite(pml).all(), "every slice must have written its partial"
+    kk = torch.cat(list(k), 1).float()
+    vv = torch.cat(list(v), 1).float()
+    ref = _attn_ref(q.float(), kk, vv).transpose(0, 1)
+    a1, a2 = _from16(o1, BF16).reshape(L, H, 64), _from16(o2, BF16).reshape(L, H, 64)
+    print(f"split-kv H{H} L{L} chunks{chunks} splits{splits}: single {_rel(a1, ref):.2e} split {_rel(a2, ref):.2e} split-vs-single {_rel(a2, a1):.2e}")
+    assert _rel(a2, ref) < 8e-3
+    assert _rel(a2, a1) < 6e-3  # both round P and O to bf16, in different groupings
+
+
 @pytest.mark.parametrize("D", [128, 256, 1024, 2048])
 def test_layernorm(dev, D):
     g = torch.Generator().manual_seed(D)

@@ -1,0 +1,25 @@
+import ctypes as C, sys, json
+import torch
+sys.path.insert(0, '.')
+from hunyuanworld_mirror_amd import _lib
+L = _lib.lib(); dev = torch.device('cuda:0')
+p = lambda t: C.c_void_p(t.data_ptr())
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def tune(k, v): assert L.wm_set_tuning(k.encode(), v) == 0
+for name, H, M, Ls in [("global_8v", 16, 8 * 1376, 8 * 1376), ("global_32v", 16, 32 * 1376, 32 * 1376)]:
+    q = (torch.randn(H, M, 64, device=dev) * 0.125).to(torch.bfloat16); k = torch.randn(H, M, 64, device=dev).to(torch.bfloat16)
+    v = torch.randn(H, M, 64, device=dev).to(torch.bfloat16); o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
+    fl = 4.0 * M * Ls * 64 * H
+    res = {}
+    for rep in range(2):
+        for label, qb in (("base", 3), ("noVALU", 11), ("quarterMFMA", 12), ("noStream", 13), ("1wave/simd", 14)):
+            tune("attn_qb", qb)
+            for _ in range(2): L.wm_op_attention(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, s)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10 if M < 20000 else 3
+            e0.record()
+            for _ in range(n): L.wm_op_attention(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, s)
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(label, []).append(round(e0.elapsed_time(e1) / n * 1e3))
+    print(json.dumps({"case": name, "us": res}), flush=True)

@@ -9,16 +9,21 @@ s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 cases = [("frame_8x1376", 16, 8 * 1376, 1376), ("dino_8x1374", 16, 8 * 1374, 1374), ("global_8v", 16, 8 * 1376, 8 * 1376),
          ("global_32v", 16, 32 * 1376, 32 * 1376)]
 if len(sys.argv) > 1: cases = [c for c in cases if c[0] in sys.argv[1:]]
+def tune(k, v): assert L.wm_set_tuning(k.encode(), v) == 0
 for name, H, M, Ls in cases:
     q = (torch.randn(H, M, 64, device=dev) * 0.125).to(torch.bfloat16); k = torch.randn(H, M, 64, device=dev).to(torch.bfloat16)
     v = torch.randn(H, M, 64, device=dev).to(torch.bfloat16); o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
-    for _ in range(2): L.wm_op_attention(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, s)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 10 if M < 20000 else 3
-    e0.record()
-    for _ in range(n): L.wm_op_attention(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, s)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    po = torch.empty(4, M, H * 64, device=dev); pml = torch.empty(4, H, M, 2, device=dev)
     fl = 4.0 * M * Ls * 64 * H
-    print(json.dumps({"case": name, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}))
+    res = {}
+    for rep in range(2):
+        for sp in (1, 2, 3, 4):
+            for _ in range(2): L.wm_op_attention_split(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, sp, p(po), p(pml), s)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10 if M < 20000 else 3
+            e0.record()
+            for _ in range(n): L.wm_op_attention_split(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, sp, p(po), p(pml), s)
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(f"splits{sp}", []).append(round(fl / (e0.elapsed_time(e1) / n) / 1e9))
+    print(json.dumps({"case": name, "tflops": res}), flush=True)
