@@ -53,7 +53,7 @@ __device__ __forceinline__ float ceil_t16(float x) {
   return y;
 }
 
-template <int T, int NW, int QB, int MINW, int DBG = 0>
+template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int QT = NW * 32 * QB;  // query rows per block; each wave owns QB blocks of 32 rows
@@ -198,55 +198,70 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
             }
       }
     }
-    // ---- online softmax in base 2 (q was pre-scaled by log2(e)/sqrt(d))
+    // ---- online softmax in base 2 (q was pre-scaled by log2(e)/sqrt(d)).  LZ: the scores already carry -m_run (MFMA),
+    // so P = 2^S' is taken FIRST and the row max only when it is needed: the lane's partial row-sum bounds every P it
+    // contains (sum <= 2^11 => each P <= 2^11: full 16-bit relative precision, fp32 l and O far from overflow; inf and
+    // NaN fail the test), and only then — or on the first tile — the max is found, O and l rescaled and P redone.
+    // Saves the 64 v_max + cross-half exchange per tile of the eager form (the VALU, not the MFMA, is the scarce pipe).
     s16x8 pf[QB][2][2];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-      float mloc = st[b][0][0];
-      if (DBG != 1) {
+      float pv[2][16], sum = 0.f;
+      bool redo = (t == t0) || !LZ;
+      if (LZ) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { pv[k2][r] = __builtin_amdgcn_exp2f(st[b][k2][r]); sum += pv[k2][r]; }
+        redo = redo || !__all(sum <= 2048.0f);
+      }
+      if (redo) {  // wave-uniform
+        float mloc = st[b][0][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[b][0][r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[b][1][r]);
-        mloc = xhalf_max(mloc);
-      }  // max of S' = S - m_run over this tile (same value in both lane halves)
-      if (t == t0 || !__all(mloc <= 0.f)) {  // wave-uniform: some row's max grew (always on the first tile)
-        const float cand = m_run[b] + (t == t0 ? mloc : fmaxf(mloc, 0.f));
-        const float m_new = ceil_t16<T>(cand);
-        const float d2 = m_new - m_run[b];
-        m_run[b] = m_new;
+        mloc = xhalf_max(mloc);  // max of S' = S - m_run over this tile (same value in both lane halves)
+        if (t == t0 || !__all(mloc <= 0.f)) {  // some row's max grew (always on the first tile)
+          const float cand = m_run[b] + (t == t0 ? mloc : fmaxf(mloc, 0.f));
+          const float m_new = ceil_t16<T>(cand);
+          const float d2 = m_new - m_run[b];
+          m_run[b] = m_new;
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[b][k2][r] -= d2;
+          if (t > t0) {
+            const float alpha = __builtin_amdgcn_exp2f(-d2);
+            l_run[b] *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) ot[b][d][r] *= alpha;
+          }
+          if (h == 0) qx[b][0] = (short)f2t<T>(-m_new);  // exact: m_new is T-representable
+        }
+        sum = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) st[b][k2][r] -= d2;
-        if (t > t0) {
-          const float alpha = __builtin_amdgcn_exp2f(-d2);
-          l_run[b] *= alpha;
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[b][d][r] *= alpha;
-        }
-        if (h == 0) qx[b][0] = (short)f2t<T>(-m_new);  // exact: m_new is T-representable
+          for (int r = 0; r < 16; ++r) {
+            pv[k2][r] = DBG == 1 ? st[b][k2][r] : __builtin_amdgcn_exp2f(st[b][k2][r]);
+            sum += pv[k2][r];
+          }
       }
+      l_run[b] += sum;
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        float pv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pv[r] = DBG == 1 ? st[b][k2][r] : __builtin_amdgcn_exp2f(st[b][k2][r]);
-          if (DBG != 1) l_run[b] += pv[r];
-        }
+      for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           uint4 u;
-          u.x = pack2(pv[8 * s2 + 0], pv[8 * s2 + 1], T);
-          u.y = pack2(pv[8 * s2 + 2], pv[8 * s2 + 3], T);
-          u.z = pack2(pv[8 * s2 + 4], pv[8 * s2 + 5], T);
-          u.w = pack2(pv[8 * s2 + 6], pv[8 * s2 + 7], T);
+          u.x = pack2(pv[k2][8 * s2 + 0], pv[k2][8 * s2 + 1], T);
+          u.y = pack2(pv[k2][8 * s2 + 2], pv[k2][8 * s2 + 3], T);
+          u.z = pack2(pv[k2][8 * s2 + 4], pv[k2][8 * s2 + 5], T);
+          u.w = pack2(pv[k2][8 * s2 + 6], pv[k2][8 * s2 + 7], T);
           pf[b][k2][s2] = __builtin_bit_cast(s16x8, u);
         }
-      }
     }
     // ---- O^T += V^T P^T : A = V^T fragment via transposed LDS reads, B = P^T (the S^T accumulator)
 #pragma unroll
@@ -309,6 +324,300 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Software-pipelined variant for long sequences (cross-view attention).
+//
+// Measured on the kernel above (tools/attn_exp.py, 32 views): deleting the softmax VALU saves 18 %, deleting the K/V
+// streaming + barrier 19 %, three quarters of the MFMAs 35 %, and one wave per SIMD is only 1.46x slower than two:
+// a wave runs QK^T -> softmax -> PV strictly one after the other and its SIMD partner fills the gaps only by chance.
+// Here the tile is processed as two 32-key halves, staggered: every half-step is ONE basic block that holds
+//    PV of the half whose P was finished in the previous half-step            ( 8 MFMAs)
+//    QK^T of the half that will be soft-maxed in the next half-step           (10 MFMAs, running max folded in)
+//    exp2 / row-sum / 16-bit pack of the current half                          (VALU, no dependence on either)
+// so the matrix pipe and the VALU of one wave overlap by construction.  The exp uses the running max the scores were
+// computed with (it is already subtracted by the MFMA); only if a score exceeds it by more than 2^THRESH, if the max
+// moved since the QK^T was issued, or on a masked tail tile, a wave-uniform branch at the END of the half-step redoes
+// that half exactly (new max, rescale O and l, recompute P).  P up to 2^THRESH keeps full 16-bit relative precision.
+// Iteration j needs {K tile j, V tile j-1}: both arrive by LDS-DMA (source-side permutation builds the swizzled K
+// rows and the [4 key][32 d] blocked V image), one barrier per iteration, no staging registers.
+template <int T, int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_sp_kernel(const WmAttnArgs p) {
+  constexpr int QB = 2, QT = 256;
+  constexpr float PBOUND = 2048.0f;  // 2^11: fine for bf16 and f16 P, and far from fp32 trouble in l and O
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [set][K|V]
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef const __attribute__((address_space(1))) void* glb_vp;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, ql = lane & 31;
+  const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
+  const int nseq = p.q_rows / p.seq_len;
+  const int tiles_per_head = tiles_per_seq * nseq;
+  const int lid = xcd_remap(blockIdx.x, tiles_per_head * p.H);
+  const int head = lid / tiles_per_head;
+  const int tile = lid - head * tiles_per_head;
+  const int seq = tile / tiles_per_seq;
+  const int qt = tile - seq * tiles_per_seq;
+  const int seq_row0 = seq * p.seq_len;
+
+  const u16* Qh = (const u16*)p.Q + (size_t)head * p.q_head_stride * 64;
+  int qrow[QB];
+  bool q_valid[QB];
+  s16x8 qf[QB][4];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    int r = qt * QT + (wave * QB + b) * 32 + ql;
+    q_valid[b] = r < p.seq_len;
+    r = q_valid[b] ? r : p.seq_len - 1;
+    qrow[b] = r;
+    const u16* qptr = Qh + (size_t)(seq_row0 + r) * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const s16x8*)(qptr + ks * 16 + h * 8);
+  }
+
+  const int seg_rows = p.kv_chunks > 1 ? p.kv_rows_per_chunk : p.seq_len;
+  const int seg_off = p.kv_chunks > 1 ? 0 : seq_row0;
+  const int ntpc = (seg_rows + KVB - 1) / KVB;
+  const int nt = ntpc * p.kv_chunks;
+  const u16* Kb = (const u16*)p.K + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
+  const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
+
+  // ---- LDS-DMA of one set: waves 0,1 bring K tile `js` (4 pieces each), waves 2,3 bring V tile `js - 1`.
+  // The loads are issued from inline asm: hipcc orders every later ds_read behind a pending LDS-DMA it can see
+  // (s_waitcnt vmcnt(0) right after the issue: +2000 cycles per iteration, measured), and the ordering this kernel
+  // needs is the explicit vmcnt(0) + barrier at the end of the iteration.
+  int nxt_c = 0, nxt_j = wave < 2 ? 0 : -1;  // (chunk, tile in chunk) of the next tile this wave loads; calls come with js = 0, 1, 2, ...
+  auto dma_set = [&](int js) {
+    const int tl = wave < 2 ? js : js - 1;  // wave-uniform
+    if (tl >= 0 && tl < nt) {
+      const u16* src = (wave < 2 ? Kb : Vb) + (size_t)nxt_c * p.kv_chunk_stride;
+      const uint32_t dst = (uint32_t)(size_t)(lds_vp)(smem + (js & 1) * 2 * TILE_B + (wave < 2 ? 0 : TILE_B) + (wave & 1) * 4096);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pc = (wave & 1) * 4 + i;
+        int key, d8;
+        if (wave < 2) {
+          key = pc * 8 + (lane >> 3);
+          d8 = (lane & 7) ^ ((key >> 1) & 7);
+        } else {
+          const int off = pc * 1024 + lane * 16, blk = off >> 8;
+          key = (blk >> 1) * 4 + ((off >> 6) & 3);
+          d8 = (blk & 1) * 4 + ((off >> 4) & 3);
+        }
+        int row = nxt_j * KVB + key;
+        row = row < seg_rows ? row : seg_rows - 1;  // clamped keys are masked (K) / multiplied by P = 0 (V)
+        const u16* g = src + (size_t)row * 64 + d8 * 8;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst + i * 1024) : "m0", "memory");
+      }
+    }
+    if (tl >= -1) { if (++nxt_j == ntpc) { nxt_j = 0; ++nxt_c; } }
+  };
+  auto valid_keys = [&](int tl) { return seg_rows - (tl % ntpc) * KVB; };  // >= KVB except on a segment's last tile
+
+  f32x16 ot[QB][2], st[QB][2];
+  s16x8 pf[QB][2][2];
+  float m_run[QB], l_run[QB];
+  bool stale[2] = {false, false};  // wave-uniform: the running max moved after this half's QK^T was issued
+  float dlt[QB][2];                // ... by this much (only read on the slow path)
+  s16x8 qx[QB], kx;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) kx[j] = 0;
+  if (h == 0) kx[0] = (short)f2t<T>(1.0f);
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qx[b][j] = 0;
+    m_run[b] = 0.f; l_run[b] = 0.f; dlt[b][0] = dlt[b][1] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[b][d][r] = 0.f;
+  }
+  const int vtr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+  // K / V^T fragments of one half-step live in registers and are read from LDS ONE HALF-STEP AHEAD (a lone wave on
+  // its SIMD has nobody to hide the ds_read latency behind; measured 8 exposed waits = ~650 cycles per half-step).
+  struct Frags { s16x8 k[4]; s16x8 v[2][2]; };
+  auto load_frags = [&](Frags& f, int hf, const char* set) {
+    const char* kt = set;
+    const char* vt = set + TILE_B;
+    const int key = hf * 32 + ql;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f.k[ks] = *(const s16x8*)(kt + key * 128 + (((2 * ks + h) ^ ((key >> 1) & 7)) << 4));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int key0 = hf * 32 + s2 * 16 + 4 * h;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const char* b0 = vt + (((key0 >> 2) * 2 + d) << 8) + vtr_lane;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(b0 + 2 * 2 * 256));
+        s16x8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+        f.v[s2][d] = vf;
+      }
+    }
+  };
+  // S'[b][hf] = K(half hf) Q^T - m_run  (keys 32 hf + (r&3) + 8(r>>2) + 4h, query ql of block b)
+  auto qk = [&](int hf, const Frags& f) {
+    const f32x16 zero = {0};
+#pragma unroll
+    for (int b = 0; b < QB; ++b) { st[b][hf] = mfma32<T>(kx, qx[b], zero); dlt[b][hf] = 0.f; }
+    stale[hf] = false;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int b = 0; b < QB; ++b) st[b][hf] = mfma32<T>(f.k[ks], qf[b][ks], st[b][hf]);
+  };
+  // O^T += V^T(half hf) P^T(half hf)
+  auto pvmm = [&](int hf, const Frags& f) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) ot[b][d] = mfma32<T>(f.v[s2][d], pf[b][hf][s2], ot[b][d]);
+  };
+  auto pack_half = [&](int b, int hf, const float* pv) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      uint4 u;
+      u.x = pack2(pv[8 * s2 + 0], pv[8 * s2 + 1], T);
+      u.y = pack2(pv[8 * s2 + 2], pv[8 * s2 + 3], T);
+      u.z = pack2(pv[8 * s2 + 4], pv[8 * s2 + 5], T);
+      u.w = pack2(pv[8 * s2 + 6], pv[8 * s2 + 7], T);
+      pf[b][hf][s2] = __builtin_bit_cast(s16x8, u);
+    }
+  };
+  // fast path: P = 2^S' with the max S' was computed with; returns whether it may be kept (per lane).  No row max is
+  // taken: the half's row-sum bounds every P of the row (sum <= 2^PBOUND => each P <= 2^PBOUND; inf / NaN fail the test)
+  float lsum[QB];
+  auto softmax_fast = [&](int hf) -> bool {
+    bool ok = true;
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float pv[16], sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(st[b][hf][r]); sum += pv[r]; }
+      pack_half(b, hf, pv);
+      lsum[b] = sum;
+      ok = ok && (sum <= PBOUND);
+    }
+    return ok;
+  };
+  // exact redo of one half: (masked) scores -> new running max -> rescale O, l -> P
+  auto softmax_slow = [&](int hf, int valid, bool first) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      const float delta = dlt[b][hf];  // the max moved after this half's QK^T was issued
+      float sv[16], mloc = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = hf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        sv[r] = key < valid ? st[b][hf][r] - delta : -INFINITY;
+        mloc = fmaxf(mloc, sv[r]);
+      }
+      mloc = xhalf_max(mloc);  // vs the current m_run; valid >= 1 on every tile, so finite
+      const float cand = m_run[b] + (first ? mloc : fmaxf(mloc, 0.f));
+      const float m_new = ceil_t16<T>(cand);
+      const float d2 = m_new - m_run[b];
+      if (!first) {
+        const float alpha = __builtin_amdgcn_exp2f(-d2);
+        l_run[b] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[b][d][r] *= alpha;
+      }
+      m_run[b] = m_new;
+      dlt[b][hf ^ 1] += d2;  // the other half's scores (if already issued) were computed with the old max
+      if (h == 0) qx[b][0] = (short)f2t<T>(-m_new);
+      float pv[16], sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pv[r] = __builtin_amdgcn_exp2f(sv[r] - d2); sum += pv[r]; }
+      pack_half(b, hf, pv);
+      lsum[b] = sum;
+    }
+  };
+  auto softmax = [&](int hf, int valid, bool first) {
+    bool ok = softmax_fast(hf);
+    int slow = (first || valid < KVB || stale[hf]) ? 1 : 0;
+    // opaque: neither may the decision be hoisted above the fast path nor the fast path sunk below the branch — either
+    // would separate the softmax VALU from the MFMAs it is meant to overlap with
+    asm volatile("" : "+v"(slow), "+v"(pf[0][hf][0]), "+v"(pf[0][hf][1]), "+v"(pf[1][hf][0]), "+v"(pf[1][hf][1]), "+v"(lsum[0]), "+v"(lsum[1]));
+    if (!__all(ok && slow == 0)) { softmax_slow(hf, valid, first); stale[hf ^ 1] = true; }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) l_run[b] += lsum[b];
+  };
+  // Schedule.  Set j = {K tile j, V tile j-1} lives in buffer j & 1.  Iteration j:
+  //   half-step A(j): softmax(j-1, half 1) || PV(j-1, half 0) + QK(j, half 0)     while reading B(j)'s fragments (set j)
+  //   vmcnt(0) [set j+1 landed], lgkmcnt(0) [own reads of set j retired], barrier
+  //   issue the DMA of set j+2 into buffer j & 1  (set j is dead: its last fragments were read in A(j))
+  //   half-step B(j): softmax(j, half 0)   || PV(j-1, half 1) + QK(j, half 1)     while reading A(j+1)'s fragments (set j+1)
+  auto set_ptr = [&](int js) { return (const char*)smem + (js & 1) * 2 * TILE_B; };
+  auto mid_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  Frags fa, fb;
+  dma_set(0);
+  mid_barrier();
+  dma_set(1);
+  // ---- iteration 0: A(0) = QK(0, half 0) only; B(0) = softmax(0, half 0) + QK(0, half 1)
+  load_frags(fa, 0, set_ptr(0));   // only the K part is meaningful (V tile -1 does not exist; never multiplied)
+  load_frags(fb, 1, set_ptr(0));
+  qk(0, fa);
+  mid_barrier();                   // set 1 landed
+  dma_set(2);
+  load_frags(fa, 0, set_ptr(1));
+  softmax(0, valid_keys(0), true);
+  qk(1, fb);
+  for (int j = 1; j < nt; ++j) {
+    const int vprev = valid_keys(j - 1), vcur = valid_keys(j);
+    load_frags(fb, 1, set_ptr(j));
+    pvmm(0, fa);
+    qk(0, fa);
+    softmax(1, vprev, false);
+    mid_barrier();
+    dma_set(j + 2);
+    load_frags(fa, 0, set_ptr(j + 1));
+    pvmm(1, fb);
+    qk(1, fb);
+    softmax(0, vcur, false);
+  }
+  // ---- iteration nt: softmax(nt-1, half 1) || PV(nt-1, half 0) ; PV(nt-1, half 1)   (set nt = {-, V tile nt-1})
+  load_frags(fb, 1, set_ptr(nt));
+  pvmm(0, fa);
+  softmax(1, valid_keys(nt - 1), false);
+  pvmm(1, fb);
+
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    const float inv = 1.0f / xhalf_sum(l_run[b]);
+    if (q_valid[b]) {
+      u16* op = (u16*)p.O + ((size_t)(seq_row0 + qrow[b]) * p.H + head) * 64;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 u;
+          u.x = pack2(ot[b][d][4 * g + 0] * inv, ot[b][d][4 * g + 1] * inv, T);
+          u.y = pack2(ot[b][d][4 * g + 2] * inv, ot[b][d][4 * g + 3] * inv, T);
+          *(uint2*)(op + 32 * d + 8 * g + 4 * h) = u;
+        }
+    }
+  }
+}
+
+template <int T, int MINW>
+hipError_t launch_sp(const WmAttnArgs& a, hipStream_t s) {
+  const int tiles_per_seq = (a.seq_len + 255) / 256;
+  const int nseq = a.q_rows / a.seq_len;
+  hipLaunchKernelGGL((attn_sp_kernel<T, MINW>), dim3(tiles_per_seq * nseq * a.H), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // O[row][head*64 + d] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s ; one thread per (row, head, 4 channels)
 template <int T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p) {
@@ -339,7 +648,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p) {
   *(uint2*)((u16*)p.O + (row * p.H + head) * 64 + d4 * 4) = u;
 }
 
-template <int T, int NW, int QB, int MINW, int DBG = 0>
+template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1>
 hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
   constexpr int QT = NW * 32 * QB;
   WmAttnArgs a = a_in;
@@ -363,7 +672,7 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
     a.kv_splits = best;
   }
   dim3 grid(tiles_per_seq * nseq * a.H * a.kv_splits), block(NW * 64);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, DBG>), grid, block, 0, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, DBG, LZ>), grid, block, 0, s, a);
   if (a.kv_splits > 1) {
     const size_t nthr = (size_t)a.q_rows * a.H * 16;
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
@@ -378,13 +687,16 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (a.seq_len <= 0 || a.q_rows % a.seq_len != 0 || a.kv_chunks < 1) return hipErrorInvalidValue;
   static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
   const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
-  const int qb = forced ? forced : (a.seq_len < 4096 ? 4 : 3);  // 64 rows per wave at 2 waves/SIMD measured best on every shape
-#ifdef WM_ATTN_DEBUG  // timing experiments only (wrong results): 11 no softmax VALU, 12 a quarter of the MFMAs, 13 no K/V streaming
-  if (qb == 11) return launch<WM_T_BF16, 4, 2, 2, 1>(a, s);
-  if (qb == 12) return launch<WM_T_BF16, 4, 2, 2, 2>(a, s);
-  if (qb == 13) return launch<WM_T_BF16, 4, 2, 2, 3>(a, s);
-  if (qb == 14) return launch<WM_T_BF16, 4, 2, 1, 0>(a, s);
+  const int qb = forced ? forced : 3;  // 64 rows per wave, 2 waves/SIMD, lazy max: fastest on every shape of the path (tools/attn_exp.py)
+#ifdef WM_ATTN_DEBUG  // timing experiments only (wrong results): 21 no softmax VALU, 22 a quarter of the MFMAs, 23 no K/V streaming, 24 one wave per SIMD
+  if (qb == 21) return launch<WM_T_BF16, 4, 2, 2, 1>(a, s);
+  if (qb == 22) return launch<WM_T_BF16, 4, 2, 2, 2>(a, s);
+  if (qb == 23) return launch<WM_T_BF16, 4, 2, 2, 3>(a, s);
+  if (qb == 24) return launch<WM_T_BF16, 4, 2, 1, 0>(a, s);
 #endif
+  if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);
+  if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0, 0>(a, s);  // eager max (A/B)
+  if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0, 0>(a, s);
   if (qb == 2) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 1>(a, s) : launch<WM_T_F16, 4, 2, 1>(a, s);
   if (qb == 3) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s) : launch<WM_T_F16, 4, 2, 2>(a, s);
   if (qb == 4) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3>(a, s) : launch<WM_T_F16, 4, 1, 3>(a, s);

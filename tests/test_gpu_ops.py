@@ -176,6 +176,38 @@ def test_attention_kv_chunks_equals_concat(dev):
     assert _rel(_from16(o, BF16).reshape(Lq, H, 64), ref) < 8e-3
 
 
+@pytest.mark.parametrize("variant", [6, 10, 4])
+def test_attention_variants(dev, variant):
+    """The non-default kernels kept for A/B (6: software-pipelined half-tile kernel with LDS-DMA, 10: eager row max,
+    4: 32 rows per wave) must stay correct: multi-tile, ragged tail, 2 sequences, plus the spike case in a late tile."""
+    L_ = _lib()
+    H, nseq, L = 4, 2, 1100
+    M = nseq * L
+    g = torch.Generator().manual_seed(variant)
+    q = torch.randn(H, M, 64, generator=g) * 0.125 * 1.5 * LOG2E
+    k = torch.randn(H, M, 64, generator=g) * 1.5
+    v = torch.randn(H, M, 64, generator=g)
+    k[:, L + 1000] = q[:, L + 17] * 8 * 30.0
+    q, k, v = [_t16(x, BF16).to(dev) for x in (q, k, v)]
+    o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L_.wm_set_tuning(b"attn_qb", variant) == 0
+    try:
+        assert L_.wm_op_attention(BF16, _p(q), _p(k), _p(v), _p(o), H, M, L, 1, 0, s) == 0
+        torch.cuda.synchronize()
+    finally:
+        L_.wm_set_tuning(b"attn_qb", -1)
+    got = _from16(o, BF16).reshape(M, H, 64)
+    ref = torch.empty(M, H, 64, device=dev)
+    for i in range(nseq):
+        sl = slice(i * L, (i + 1) * L)
+        ref[sl] = _attn_ref(q[:, sl].float(), k[:, sl].float(), v[:, sl].float()).transpose(0, 1)
+    assert torch.isfinite(got).all()
+    e = _rel(got, ref)
+    print(f"attention variant {variant}: {e:.2e}")
+    assert e < 8e-3
+
+
 @pytest.mark.parametrize("H,L,chunks,splits", [(4, 2752, 1, 2), (2, 2200, 1, 4), (3, 1100, 2, 2), (2, 5504, 1, 3)])
 def test_attention_split_kv(dev, H, L, chunks, splits):
     """Split-KV (partials + combine pass) == the single-pass kernel == fp32 softmax; the spike key sits in the LAST
