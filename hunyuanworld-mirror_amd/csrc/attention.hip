@@ -53,12 +53,13 @@ __device__ __forceinline__ float ceil_t16(float x) {
   return y;
 }
 
-template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1>
+template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1, int STG = 1>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int QT = NW * 32 * QB;  // query rows per block; each wave owns QB blocks of 32 rows
   constexpr int CPT = 512 / NT;     // 16-B chunks per thread per tile (K and V each)
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K|V]
+  constexpr int NBUF = STG == 2 ? 3 : 2;  // STG 2: three-deep ring, tiles fetched two ahead
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_B];  // [buf][K|V]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, ql = lane & 31;
@@ -99,6 +100,32 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   const u16* Kb = (const u16*)p.K + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
 
+  // STG 1: tiles stream by LDS-DMA (1-KiB pieces; the source-side permutation builds the swizzled K rows and the
+  // blocked V image; issued from inline asm — hipcc would order every later ds_read behind a DMA it can see with a
+  // vmcnt(0)); the wait is the explicit one before the barrier.  STG 0: global -> registers -> ds_write.
+  typedef __attribute__((address_space(3))) void* lds_vp0;
+  int dma_c = 0, dma_j = 0;  // (chunk, tile in chunk) of the next tile to fetch: tiles are fetched in order from t0
+  auto dma_tile = [&](int buf) {
+    const u16* kp = Kb + (size_t)dma_c * p.kv_chunk_stride;
+    const u16* vp = Vb + (size_t)dma_c * p.kv_chunk_stride;
+    const uint32_t dst = (uint32_t)(size_t)(lds_vp0)(smem + buf * 2 * TILE_B);
+    constexpr int PPW = 8 / NW;  // pieces of K (and of V) per wave
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave * PPW + i;
+      const int kkey = pc * 8 + (lane >> 3), kd8 = (lane & 7) ^ ((kkey >> 1) & 7);
+      const int off = pc * 1024 + lane * 16, blk = off >> 8;
+      const int vkey = (blk >> 1) * 4 + ((off >> 6) & 3), vd8 = (blk & 1) * 4 + ((off >> 4) & 3);
+      int kr = dma_j * KVB + kkey, vr = dma_j * KVB + vkey;
+      kr = kr < seg_rows ? kr : seg_rows - 1;  // clamped keys: masked (K), multiplied by P = 0 (V)
+      vr = vr < seg_rows ? vr : seg_rows - 1;
+      const u16* gk = kp + (size_t)kr * 64 + kd8 * 8;
+      const u16* gv = vp + (size_t)vr * 64 + vd8 * 8;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gk), "s"(dst + pc * 1024) : "m0", "memory");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gv), "s"(dst + TILE_B + pc * 1024) : "m0", "memory");
+    }
+    if (++dma_j == ntpc) { dma_j = 0; ++dma_c; }
+  };
   uint4 kreg[CPT], vreg[CPT];
   auto load_tile = [&](int t) {
     const int c = t / ntpc, j = t - c * ntpc;
@@ -153,18 +180,31 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
 
   // this block's slice of the key tiles (every slice is non-empty: the launcher keeps kv_splits <= ntiles)
   const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
-  load_tile(t0);
-  store_tile(0);
+  constexpr int DPW = 2 * (8 / NW);  // DMA instructions per wave per tile
+  if (STG) {
+    dma_c = t0 / ntpc; dma_j = t0 - dma_c * ntpc;
+    dma_tile(0);
+    if (STG == 2 && t0 + 1 < t1) { dma_tile(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    load_tile(t0);
+    store_tile(0);
+  }
   __syncthreads();
 
   // per-lane constant part of the transposed V read address (see header)
   const int vtr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
   for (int t = t0; t < t1; ++t) {
-    const int cur = (t - t0) & 1;
+    const int cur = STG == 2 ? (t - t0) % 3 : (t - t0) & 1;
     const char* kt = smem + cur * 2 * TILE_B;
     const char* vt = kt + TILE_B;
-    if (t + 1 < t1 && DBG != 3) load_tile(t + 1);  // global -> regs, hidden under the MFMA phase
+    if (STG == 2) {
+      if (t + 2 < t1) dma_tile((t - t0 + 2) % 3);  // the buffer of tile t-1: everybody passed the barrier that ended it
+    } else if (t + 1 < t1 && DBG != 3) {
+      if (STG) dma_tile(cur ^ 1);  // everybody passed the barrier that ended tile t-1: the other buffer is free
+      else load_tile(t + 1);       // global -> regs, hidden under the MFMA phase
+    }
 
     // ---- S^T = K Q^T : st[b][k2][r] = S[key = 32k2 + (r&3)+8(r>>2)+4h][q = ql of block b]
     f32x16 st[QB][2];
@@ -283,7 +323,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
         }
       }
     if (DBG != 3) {
-      if (t + 1 < t1) store_tile(cur ^ 1);
+      if (STG == 2) {  // tile t+1 must have landed; tile t+2 (if any) may stay in flight
+        if (t + 2 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (t + 1 < t1) store_tile(cur ^ 1);
       __syncthreads();
     }
   }
@@ -648,7 +692,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p) {
   *(uint2*)((u16*)p.O + (row * p.H + head) * 64 + d4 * 4) = u;
 }
 
-template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1>
+template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1, int STG = 1>
 hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
   constexpr int QT = NW * 32 * QB;
   WmAttnArgs a = a_in;
@@ -672,7 +716,7 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
     a.kv_splits = best;
   }
   dim3 grid(tiles_per_seq * nseq * a.H * a.kv_splits), block(NW * 64);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, DBG, LZ>), grid, block, 0, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, DBG, LZ, STG>), grid, block, 0, s, a);
   if (a.kv_splits > 1) {
     const size_t nthr = (size_t)a.q_rows * a.H * 16;
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
@@ -697,6 +741,8 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);
   if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0, 0>(a, s);  // eager max (A/B)
   if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0, 0>(a, s);
+  if (qb == 13) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0, 1, 2>(a, s) : launch<WM_T_F16, 4, 2, 2, 0, 1, 2>(a, s);  // 3-deep DMA ring
+  if (qb == 12) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0, 1, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0, 1, 0>(a, s);  // register staging (A/B)
   if (qb == 2) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 1>(a, s) : launch<WM_T_F16, 4, 2, 1>(a, s);
   if (qb == 3) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s) : launch<WM_T_F16, 4, 2, 2>(a, s);
   if (qb == 4) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3>(a, s) : launch<WM_T_F16, 4, 1, 3>(a, s);
