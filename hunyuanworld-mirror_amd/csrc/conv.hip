@@ -127,8 +127,11 @@ __global__ __launch_bounds__(256) void conv_kernel(const WmConvArgs p) {
   const u16* W = (const u16*)p.w;
   load_a(0);
   stage_w<BK, BN>(W, K, n0, p.Cout, 0, smem + A_BYTES, wave, lane);
+  // Explicit drain BEFORE the register loads are consumed: (i) hipcc does not reliably drain LDS-DMA before a barrier,
+  // (ii) LDS-DMA and register loads return out of order with respect to each other, so a compiler-counted vmcnt(N > 0)
+  // for the register loads is not safe while DMA is in flight (see conv3x3.hip).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   store_a(smem);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit LDS-DMA drain (see conv3x3.hip)
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const WmConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<T>(a[i], b[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_a(nA);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt + 1 < nk) store_a(nA);
     __syncthreads();
     cur ^= 1;
   }
@@ -215,6 +218,10 @@ hipError_t wm_launch_conv3x3(const WmConvArgs& a, hipStream_t s);
 hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s) {
   if (a.N <= 0) return hipSuccess;
   static const bool no_halo = getenv("WM_CONV_GENERIC") != nullptr;
+  if (a.up_hs > 0) {  // fused input upsample exists in the halo kernel only; callers test wm_conv3x3_applicable first
+    if (!wm_conv3x3_applicable(a) || a.up_ws <= 0 || (a.up_addx && (a.Cin & 15))) return hipErrorInvalidValue;
+    return wm_launch_conv3x3(a, s);
+  }
   if (!no_halo && wm_conv3x3_applicable(a)) return wm_launch_conv3x3(a, s);
   if (a.Cin % 32 != 0 || a.ksize < 1) return hipErrorInvalidValue;
   if (a.Ho != (a.Hi + 2 * a.pad - a.ksize) / a.stride + 1 || a.Wo != (a.Wi + 2 * a.pad - a.ksize) / a.stride + 1)

@@ -47,47 +47,91 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   const int ty = lid % tiles_y;
   const int n = lid / tiles_y;
   const int y0 = ty * TP, x0 = tx * TP, n0 = ct * BN;
-  const float* xin = p.x + (size_t)n * H * W * Cin;
+  const float* xin = p.x + (size_t)n * H * W * Cin;  // re-pointed below in up mode
   const u16* Wt = (const u16*)p.w;
   const int K = 9 * Cin;
 
-  // ---- halo staging (global fp32 -> regs -> 16-bit LDS)
-  float4 hreg[HPT][2];
-  auto halo_load = [&](int cc) {
-#pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int id = tid + i * 512;
-      const int hr = id >> 3, ch = id & 7;
-      const int hy = hr / HW_, hx = hr - hy * HW_;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      if (id < HCH && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        const float* s = xin + ((size_t)iy * W + ix) * Cin + cc * 64 + ch * 8;
-        hreg[i][0] = *(const float4*)s;
-        hreg[i][1] = *(const float4*)(s + 4);
-      } else {
-        hreg[i][0] = make_float4(0, 0, 0, 0);
-        hreg[i][1] = make_float4(0, 0, 0, 0);
+  // ---- halo staging (global fp32 -> regs -> 16-bit LDS), one item (= one 8-channel chunk of one halo pixel) per
+  // thread per call: chunk cc+1's halo is brought in over taps 0..HPT of chunk cc, an item's loads issued before one
+  // tap's MFMAs and converted / written to the other halo buffer at the start of the next tap.  With up_hs > 0 the item is interpolated on
+  // the fly from the low-resolution source (4 corner loads, the weights of bilinear_kernel) — the upsampled tensor is
+  // never written to HBM.
+  const bool up = p.up_hs > 0;
+  const float usy = up && H > 1 ? (float)(p.up_hs - 1) / (float)(H - 1) : 0.f;
+  const float usx = up && W > 1 ? (float)(p.up_ws - 1) / (float)(W - 1) : 0.f;
+  if (up) xin = p.x + (size_t)n * p.up_hs * p.up_ws * Cin;
+  float4 hv[4][2];     // plain: hv[0]; up: the 4 corners
+  float4 ha[2];        // position-table add (up mode with tables)
+  float hw[4];         // corner weights
+  bool h_in = false;   // the halo pixel lies inside the image
+  auto halo_load = [&](int cc, int i) {
+    const int id = tid + i * 512;
+    const int hr = id >> 3, ch = id & 7;
+    const int hy = hr / HW_, hx = hr - hy * HW_;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    h_in = id < HCH && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    if (!h_in) return;
+    const int c0 = cc * 64 + ch * 8;
+    if (!up) {
+      const float* s = xin + ((size_t)iy * W + ix) * Cin + c0;
+      hv[0][0] = *(const float4*)s;
+      hv[0][1] = *(const float4*)(s + 4);
+    } else {
+      const float fy = usy * iy, fx = usx * ix;
+      int ya = (int)fy, xa = (int)fx;
+      ya = ya < p.up_hs - 1 ? ya : p.up_hs - 1;
+      xa = xa < p.up_ws - 1 ? xa : p.up_ws - 1;
+      const int yb = ya < p.up_hs - 1 ? ya + 1 : ya, xb = xa < p.up_ws - 1 ? xa + 1 : xa;
+      const float wy = fy - ya, wx = fx - xa;
+      hw[0] = (1.f - wy) * (1.f - wx); hw[1] = (1.f - wy) * wx; hw[2] = wy * (1.f - wx); hw[3] = wy * wx;
+      const float* s00 = xin + ((size_t)ya * p.up_ws + xa) * Cin + c0;
+      const float* s01 = xin + ((size_t)ya * p.up_ws + xb) * Cin + c0;
+      const float* s10 = xin + ((size_t)yb * p.up_ws + xa) * Cin + c0;
+      const float* s11 = xin + ((size_t)yb * p.up_ws + xb) * Cin + c0;
+      hv[0][0] = *(const float4*)s00; hv[0][1] = *(const float4*)(s00 + 4);
+      hv[1][0] = *(const float4*)s01; hv[1][1] = *(const float4*)(s01 + 4);
+      hv[2][0] = *(const float4*)s10; hv[2][1] = *(const float4*)(s10 + 4);
+      hv[3][0] = *(const float4*)s11; hv[3][1] = *(const float4*)(s11 + 4);
+      if (p.up_addx) {
+        const int half = Cin >> 1;
+        const float* t = c0 < half ? p.up_addx + (size_t)ix * half + c0 : p.up_addy + (size_t)iy * half + (c0 - half);
+        ha[0] = *(const float4*)t; ha[1] = *(const float4*)(t + 4);
       }
     }
   };
-  auto halo_store = [&](char* dst) {
+  auto halo_store = [&](char* dst, int i) {
+    const int id = tid + i * 512;
+    if (id >= HCH) return;
+    const int hr = id >> 3, ch = id & 7;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (h_in) {
+      if (!up) {
+        v[0] = hv[0][0].x; v[1] = hv[0][0].y; v[2] = hv[0][0].z; v[3] = hv[0][0].w;
+        v[4] = hv[0][1].x; v[5] = hv[0][1].y; v[6] = hv[0][1].z; v[7] = hv[0][1].w;
+      } else {
 #pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int id = tid + i * 512;
-      if (id >= HCH) continue;
-      const int hr = id >> 3, ch = id & 7;
-      float v[8] = {hreg[i][0].x, hreg[i][0].y, hreg[i][0].z, hreg[i][0].w, hreg[i][1].x, hreg[i][1].y, hreg[i][1].z, hreg[i][1].w};
+        for (int q = 0; q < 2; ++q) {
+          v[4 * q + 0] = hw[0] * hv[0][q].x + hw[1] * hv[1][q].x + hw[2] * hv[2][q].x + hw[3] * hv[3][q].x;
+          v[4 * q + 1] = hw[0] * hv[0][q].y + hw[1] * hv[1][q].y + hw[2] * hv[2][q].y + hw[3] * hv[3][q].y;
+          v[4 * q + 2] = hw[0] * hv[0][q].z + hw[1] * hv[1][q].z + hw[2] * hv[2][q].z + hw[3] * hv[3][q].z;
+          v[4 * q + 3] = hw[0] * hv[0][q].w + hw[1] * hv[1][q].w + hw[2] * hv[2][q].w + hw[3] * hv[3][q].w;
+        }
+        if (p.up_addx) {
+          v[0] += ha[0].x; v[1] += ha[0].y; v[2] += ha[0].z; v[3] += ha[0].w;
+          v[4] += ha[1].x; v[5] += ha[1].y; v[6] += ha[1].z; v[7] += ha[1].w;
+        }
+      }
       if (p.relu_in) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      uint4 u;
-      u.x = (uint32_t)f2t<T>(v[0]) | ((uint32_t)f2t<T>(v[1]) << 16);
-      u.y = (uint32_t)f2t<T>(v[2]) | ((uint32_t)f2t<T>(v[3]) << 16);
-      u.z = (uint32_t)f2t<T>(v[4]) | ((uint32_t)f2t<T>(v[5]) << 16);
-      u.w = (uint32_t)f2t<T>(v[6]) | ((uint32_t)f2t<T>(v[7]) << 16);
-      *(uint4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = u;
     }
+    uint4 u;
+    u.x = (uint32_t)f2t<T>(v[0]) | ((uint32_t)f2t<T>(v[1]) << 16);
+    u.y = (uint32_t)f2t<T>(v[2]) | ((uint32_t)f2t<T>(v[3]) << 16);
+    u.z = (uint32_t)f2t<T>(v[4]) | ((uint32_t)f2t<T>(v[5]) << 16);
+    u.w = (uint32_t)f2t<T>(v[6]) | ((uint32_t)f2t<T>(v[7]) << 16);
+    *(uint4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = u;
   };
   // ---- weight tile (chunk cc, tap) by LDS-DMA, swizzle on the source address
   auto stage_w = [&](int cc, int tap, char* dst) {
@@ -117,9 +161,14 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   }
 
   const int nchunks = Cin / 64;
-  halo_load(0);
+  static_assert(HPT <= 7, "one halo item per tap, stored one tap later");
+#pragma unroll 1
+  for (int i = 0; i < HPT; ++i) {
+    halo_load(0, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    halo_store(hbuf, i);
+  }
   stage_w(0, 0, bbuf);
-  halo_store(hbuf);
   int kt = 0;
   for (int cc = 0; cc < nchunks; ++cc) {
     const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
@@ -128,9 +177,14 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
       // emitted lgkmcnt(0) only), so the vmcnt(0) is explicit.  Also publishes the halo writes.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      // halo item tap-1 of the next chunk: its global loads were issued one tap ago and are covered by the vmcnt(0)
+      // above.  (Never consume a register load on a compiler-counted vmcnt(N > 0) while LDS-DMA is in flight: DMA and
+      // register loads return out of order with respect to each other — measured: 16-lane groups with stale data.)
+      if (tap >= 1 && tap <= HPT && cc + 1 < nchunks) halo_store(hbuf + ((cc + 1) & 1) * HALO_BYTES, tap - 1);
       const bool last = cc + 1 == nchunks && tap == 8;
       if (!last) stage_w(tap == 8 ? cc + 1 : cc, tap == 8 ? 0 : tap + 1, bbuf + ((kt + 1) & 1) * B_BYTES);
-      if (tap == 6 && cc + 1 < nchunks) halo_load(cc + 1);
+      const bool stage_h = tap < HPT && cc + 1 < nchunks;  // wave-uniform
+      if (stage_h) halo_load(cc + 1, tap);
       const char* tB = bbuf + (kt & 1) * B_BYTES;
       const int toff = (tap / 3) * HW_ + (tap % 3);
 #pragma unroll
@@ -152,7 +206,6 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(b[j], a[i], acc[i][j]);  // D[cout][pixel]
       }
-      if (tap == 8 && cc + 1 < nchunks) halo_store(hbuf + ((cc + 1) & 1) * HALO_BYTES);
     }
   }
 

@@ -108,7 +108,13 @@ struct WmConvArgs {
   float* y;            // NHWC f32 [N][Ho][Wo][Cout]
   int N, Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad;
   int relu_in, resid_relu, relu_out, dtype;
+  // Fused align_corners bilinear resize of the INPUT (3x3 / s1 / p1 halo kernel only): when up_hs > 0, x is
+  // [N][up_hs][up_ws][Cin] and the conv sees interpolate(x, (Hi, Wi)) (+ the separable position tables: channel
+  // c < Cin/2 gets up_addx[ix][c], the others up_addy[iy][c - Cin/2]) without that tensor ever being stored.
+  int up_hs, up_ws;
+  const float* up_addx; const float* up_addy;
 };
+bool wm_conv3x3_applicable(const WmConvArgs& a);
 hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ camera head / small fp32 ops (small.hip)
@@ -127,6 +133,6 @@ hipError_t wm_launch_cam_matrices(const float* params, float* poses, float* intr
 
 // Process-wide tuning overrides (wm_set_tuning in the C ABI; tests and A/B tools).  -1 = not set: the kernel's
 // launcher falls back to its environment variable, then to its built-in choice.
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

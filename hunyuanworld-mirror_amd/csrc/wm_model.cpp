@@ -419,7 +419,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -835,12 +835,16 @@ wm_status camera_head(Ctx& c, float* out_params) {
   return WM_OK;
 }
 
+// up_hs > 0: x is [N][up_hs][up_ws][Cin] and the conv runs on its align_corners bilinear resize to (Hi, Wi)
+// (+ position tables), fused into the 3x3 halo kernel's input staging.
 wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, const float* resid, bool resid_relu, const float* resid2,
-               float* y, int N, int Hi, int Wi, int ks, int stride, int pad, bool relu_in) {
+               float* y, int N, int Hi, int Wi, int ks, int stride, int pad, bool relu_in, int up_hs = 0, int up_ws = 0,
+               const float* up_addx = nullptr, const float* up_addy = nullptr) {
   const Weight* w = W(c.h, wname + ".weight");
   if (!w || !w->w16) return fail(c.h, WM_ERR_STATE, "missing conv weight " + wname);
   WmConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.up_hs = up_hs; a.up_ws = up_ws; a.up_addx = up_addx; a.up_addy = up_addy;
   a.x = x; a.w = w->w16; a.bias = bias ? F(c.h, wname + ".bias") : nullptr; a.resid = resid; a.resid2 = resid2; a.y = y;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = (int)w->shape[1]; a.Cout = (int)w->shape[0]; a.ksize = ks; a.stride = stride; a.pad = pad;
   a.Ho = (Hi + 2 * pad - ks) / stride + 1; a.Wo = (Wi + 2 * pad - ks) / stride + 1;
@@ -919,6 +923,10 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     if (st) return st;
     LCHK(c, wm_launch_bilinear(S0, S2, n, Hs[3], Ws[3], Hs[2], Ws[2], F_, nullptr, nullptr, c.s));
     float* cur = S2;  // output of the previous fusion block at level L
+    // the two big resizes feed only a 3x3 conv: fuse them into that conv's input staging when the halo kernel applies
+    const bool fuse_on = wm_tuning[WM_TUNE_CONV_FUSE_UP] != 0 && getenv("WM_CONV_GENERIC") == nullptr;
+    const bool fuse_up1 = fuse_on && F_ % 64 == 0 && 4 * Hs[0] * Ws[0] >= 256;
+    const bool fuse_up2 = fuse_on && !is_gs && (F_ / 2) % 64 == 0;
     for (int L = 2; L >= 0; --L) {  // refinenet3 (level 2), refinenet2 (level 1), refinenet1 (level 0)
       const std::string rp = sc + "refinenet" + std::to_string(L + 1) + ".";
       float* others[3];
@@ -933,6 +941,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       const int Ho = L > 0 ? Hs[L - 1] : 2 * Hs[0], Wo = L > 0 ? Ws[L - 1] : 2 * Ws[0];
       st = conv(c, others[2], rp + "out_conv", true, nullptr, false, nullptr, others[0], n, Hs[L], Ws[L], 1, 1, 0, false);
       if (st) return st;
+      if (L == 0 && fuse_up1) { cur = others[0]; break; }  // the last resize is fused into output_conv1's input staging
       LCHK(c, wm_launch_bilinear(others[0], others[1], n, Hs[L], Ws[L], Ho, Wo, F_, nullptr, nullptr, c.s));
       cur = others[1];
     }
@@ -942,13 +951,19 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       int k = 0;
       for (float* b : {S0, S1, S2, S3}) if (b != cur) others[k++] = b;
     }
-    st = conv(c, cur, sc + "output_conv1", true, nullptr, false, nullptr, others[0], n, H8, W8, 3, 1, 1, false);
+    if (fuse_up1) st = conv(c, cur, sc + "output_conv1", true, nullptr, false, nullptr, others[0], n, H8, W8, 3, 1, 1, false, Hs[0], Ws[0]);
+    else st = conv(c, cur, sc + "output_conv1", true, nullptr, false, nullptr, others[0], n, H8, W8, 3, 1, 1, false);
     if (st) return st;
     const int Ho = gh * cf.patch_size, Wo = gw * cf.patch_size;
     float* fused = others[1];
-    LCHK(c, wm_launch_bilinear(others[0], fused, n, H8, W8, Ho, Wo, F_ / 2, B<float>(h, is_gs ? "gs_posx" : "dpt_posx"),
-                               B<float>(h, is_gs ? "gs_posy" : "dpt_posy"), c.s));
-    st = conv(c, fused, sc + "output_conv2.0", true, nullptr, false, nullptr, others[2], n, Ho, Wo, 3, 1, 1, false);
+    const float* posx = B<float>(h, is_gs ? "gs_posx" : "dpt_posx");
+    const float* posy = B<float>(h, is_gs ? "gs_posy" : "dpt_posy");
+    if (fuse_up2) {  // (the GS branch also needs the resized tensor itself: input_merger accumulates into it)
+      st = conv(c, others[0], sc + "output_conv2.0", true, nullptr, false, nullptr, others[2], n, Ho, Wo, 3, 1, 1, false, H8, W8, posx, posy);
+    } else {
+      LCHK(c, wm_launch_bilinear(others[0], fused, n, H8, W8, Ho, Wo, F_ / 2, posx, posy, c.s));
+      st = conv(c, fused, sc + "output_conv2.0", true, nullptr, false, nullptr, others[2], n, Ho, Wo, 3, 1, 1, false);
+    }
     if (st) return st;
     const size_t npix = (size_t)n * Ho * Wo, voff = (size_t)v0 * Ho * Wo;
     LCHK(c, wm_launch_dpt_tail(others[2], F(h, sc + "output_conv2.2.weight"), F(h, sc + "output_conv2.2.bias"),
@@ -1262,6 +1277,15 @@ extern "C" wm_status wm_op_conv(int dtype, const float* x, const void* w16, cons
   a.x = x; a.w = w16; a.bias = bias; a.resid = resid; a.resid2 = resid2; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
   a.ksize = ksize; a.stride = stride; a.pad = pad; a.Ho = (Hi + 2 * pad - ksize) / stride + 1; a.Wo = (Wi + 2 * pad - ksize) / stride + 1;
   a.relu_in = relu_in; a.resid_relu = resid_relu; a.dtype = dtype;
+  return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_conv3x3_up(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi, int Wi,
+                                      int Cin, int Cout, const float* addx, const float* addy, void* stream) {
+  WmConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w16; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.ksize = 3; a.stride = 1; a.pad = 1;
+  a.Ho = Hi; a.Wo = Wi; a.dtype = dtype; a.up_hs = Hs; a.up_ws = Ws; a.up_addx = addx; a.up_addy = addy;
+  if (getenv("WM_DBG_LATE")) a.relu_out = 7;
   return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
 extern "C" wm_status wm_op_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {

@@ -129,6 +129,11 @@ wm_status wm_op_qkv_post(int dtype, const float* qkv, void* q, void* k, void* v,
 wm_status wm_op_conv(int dtype, const float* x, const void* w16, const float* bias, const float* resid, const float* resid2,
                      float* y, int N, int Hi, int Wi, int Cin, int Cout, int ksize, int stride, int pad, int relu_in,
                      int resid_relu, void* stream);
+/* 3x3 / stride 1 / pad 1 conv of interpolate(x, (Hi, Wi), bilinear, align_corners=True) [+ separable position tables
+ * addx [Wi][Cin/2], addy [Hi][Cin/2] or NULL], x NHWC [N][Hs][Ws][Cin]: the resize (dense_head.py:217-225) is fused
+ * into the conv's input staging, the resized tensor is never stored.  Cin % 64 == 0, Cout % 4 == 0. */
+wm_status wm_op_conv3x3_up(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi, int Wi,
+                           int Cin, int Cout, const float* addx, const float* addy, void* stream);
 wm_status wm_op_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream);
 wm_status wm_op_linear_f32(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int ldx, int pre_act,
                            int post_act, void* stream);

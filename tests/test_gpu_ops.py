@@ -368,6 +368,36 @@ def test_conv(dev, Cin, Cout, ks, stride, Hh, Ww):
         assert e < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,Hs,Ws,Hi,Wi,pos", [(256, 128, 20, 16, 40, 32, False), (128, 32, 40, 32, 70, 56, True),
+                                                    (64, 64, 9, 11, 33, 40, True), (256, 128, 148, 148, 296, 296, False)])
+def test_conv3x3_fused_upsample(dev, Cin, Cout, Hs, Ws, Hi, Wi, pos):
+    """conv3x3(resize(x) [+ pos tables]) with the resize fused into the halo staging == torch interpolate
+    (align_corners=True) + conv on 16-bit-rounded inputs, and == the unfused bilinear op followed by the conv op."""
+    dt = F16
+    g = torch.Generator().manual_seed(Cin + Hi)
+    N = 2
+    x = torch.randn(N, Hs, Ws, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    w = _t16(w, dt).float().to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    w16 = _t16(w.permute(0, 2, 3, 1).contiguous(), dt)
+    addx = torch.randn(Wi, Cin // 2, generator=g).to(dev) if pos else None
+    addy = torch.randn(Hi, Cin // 2, generator=g).to(dev) if pos else None
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = torch.empty(N, Hi, Wi, Cout, device=dev)
+    assert _lib().wm_op_conv3x3_up(dt, _p(x), _p(w16), _p(b), _p(y), N, Hs, Ws, Hi, Wi, Cin, Cout, _p(addx) if pos else None,
+                                   _p(addy) if pos else None, s) == 0
+    torch.cuda.synchronize()
+    up = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(Hi, Wi), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    if pos:
+        up = up + torch.cat([addx[None, None].expand(N, Hi, Wi, Cin // 2), addy[None, :, None].expand(N, Hi, Wi, Cin // 2)], -1)
+    ref = _conv_ref(up.contiguous(), w, b, 1, 1, 0, None, False, None, dt)
+    e = _rel(y, ref)
+    print(f"fused upsample conv {Cin}->{Cout} {Hs}x{Ws}->{Hi}x{Wi} pos{pos}: {e:.2e}")
+    # the interpolated value is rounded to 16 bit: a different fp32 summation order flips a few roundings
+    assert e < 3e-4
+
+
 def test_bilinear(dev):
     x = torch.randn(2, 19, 19, 64).to(dev)
     for (Ho, Wo) in ((37, 37), (40, 31), (38, 38)):
