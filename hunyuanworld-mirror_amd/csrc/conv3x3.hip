@@ -26,7 +26,7 @@ constexpr int HPT = (HCH + 511) / 512;      // chunks per thread (6)
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int T, int WM, int WN, int TM, int TN>
+template <int T, int WM, int WN, int TM, int TN, int PP = 0>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   constexpr int BN = WN * TN * 32;
   constexpr int B_BYTES = BN * 128;
@@ -169,6 +169,67 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
     halo_store(hbuf, i);
   }
   stage_w(0, 0, bbuf);
+  if constexpr (PP) {
+    // Ping-pong main loop (same idea as gemm_pp_kernel): the (chunk, tap) step is two phases of 2 k-slices = 16 MFMAs;
+    // every phase is {load stage: ds_read the phase's fragments | barrier | MFMA stage | barrier} and waves 4-7 run
+    // one barrier behind waves 0-3, so on every SIMD one wave multiplies while its partner reads LDS / issues the
+    // next weights' DMA / stages a halo item.  Weights(kt+1) are issued in phase 0 and drained by every wave
+    // (vmcnt(0), which also covers the halo item's register loads — see the ordering rule above) in phase 1, before
+    // a barrier all readers pass; own ds_reads are retired (lgkmcnt(0)) before the barrier that ends a load stage.
+    static_assert(!PP || (TM == 4 && TN == 2), "ping-pong loop is written for the 128 px x 64 ch wave tile");
+    const int grp = wave >> 2;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int kt = 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+      const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
+      for (int tap = 0; tap < 9; ++tap, ++kt) {
+        const char* tB = bbuf + (kt & 1) * B_BYTES;
+        const int toff = (tap / 3) * HW_ + (tap % 3);
+        const bool last = cc + 1 == nchunks && tap == 8;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          s16x8 a[2][TM], b[2][TN];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int ch = 2 * (2 * ph + q) + (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int row = (wn * TN + j) * 32 + (lane & 31);
+              b[q][j] = *(const s16x8*)(tB + row * 128 + ((ch ^ swz(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const int hr = hbase[i] + toff;
+              a[q][i] = *(const s16x8*)(hcur + hr * 128 + ((ch ^ swz(hr)) << 4));
+            }
+          }
+          if (ph == 0) {
+            if (tap >= 1 && tap <= HPT && cc + 1 < nchunks) halo_store(hbuf + ((cc + 1) & 1) * HALO_BYTES, tap - 1);
+            if (!last) stage_w(tap == 8 ? cc + 1 : cc, tap == 8 ? 0 : tap + 1, bbuf + ((kt + 1) & 1) * B_BYTES);
+            if (tap < HPT && cc + 1 < nchunks) halo_load(cc + 1, tap);
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(b[q][j], a[q][i], acc[i][j]);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
   int kt = 0;
   for (int cc = 0; cc < nchunks; ++cc) {
     const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
@@ -209,6 +270,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
     }
   }
 
+  }  // lock-step loop
   // ---- epilogue: lane = pixel (lane&31) of tile i, regs 4g..4g+3 <-> channels 8g + 4h + {0..3}
   const int h4 = (lane >> 5) * 4;
 #pragma unroll
@@ -245,25 +307,35 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   }
 }
 
-template <int T, int WM, int WN, int TM, int TN>
+template <int T, int WM, int WN, int TM, int TN, int PP = 0>
 hipError_t launch_cfg(const WmConvArgs& a, hipStream_t s) {
   constexpr int BN = WN * TN * 32;
   const size_t shm = 2 * HALO_BYTES + 2 * BN * 128;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, WM, WN, TM, TN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
   const int nblk = a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP) * ((a.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, TM, TN>), dim3(nblk), dim3(512), shm, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, TM, TN, PP>), dim3(nblk), dim3(512), shm, s, a);
   return hipGetLastError();
 }
 
 template <int T>
 hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
-  if (a.Cout > 128) return launch_cfg<T, 2, 4, 4, 2>(a, s);   // 256 px x 256 ch
-  if (a.Cout > 32) return launch_cfg<T, 4, 2, 2, 2>(a, s);    // 256 px x 128 ch
-  return launch_cfg<T, 8, 1, 1, 1>(a, s);                     // 256 px x 32 ch
+  // output-channel tile: as wide as Cout allows, but narrower while the launch would cover less than half the chip
+  // (the 19^2 and 37^2 DPT levels: 32 / 72 pixel tiles; measured with tools/bench_conv.py: 37^2 161 -> 249 TF/s at
+  // 128 channels, 19^2 46 -> 112 at 64; 74^2 with 200 tiles stays fastest at 256) — the halo is then re-staged per
+  // channel tile, from L2.  conv_bn (tuning) forces a width.
+  static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+  const long ptiles = (long)a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP);
+  int bn = a.Cout > 128 ? 256 : a.Cout > 64 ? 128 : a.Cout > 32 ? 64 : 32;
+  while (bn > 64 && 2 * ptiles * ((a.Cout + bn - 1) / bn) < ncu) bn >>= 1;
+  if (wm_tuning[WM_TUNE_CONV_BN] > 0) bn = wm_tuning[WM_TUNE_CONV_BN];
+  if (bn >= 256) return wm_tuning[WM_TUNE_CONV_PP] == 1 ? launch_cfg<T, 2, 4, 4, 2, 1>(a, s) : launch_cfg<T, 2, 4, 4, 2, 0>(a, s);  // 256 px x 256 ch
+  if (bn >= 128) return launch_cfg<T, 4, 2, 2, 2>(a, s);   // 256 px x 128 ch
+  if (bn >= 64) return launch_cfg<T, 4, 2, 2, 1>(a, s);    // 256 px x 64 ch
+  return launch_cfg<T, 8, 1, 1, 1>(a, s);                  // 256 px x 32 ch
 }
 
 }  // namespace
