@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   static_assert(WM * WN == 8 && WM * TM * 32 == 256, "8 waves x 256 pixels");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 halo][2 B]
   char* hbuf = smem;
-  char* bbuf = smem + 2 * HALO_BYTES;
+  char* bbuf = smem + (PP == 2 ? 1 : 2) * HALO_BYTES;  // PP 2 (narrow): one halo buffer, then all 9 taps' weights
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -60,11 +60,16 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   const float usy = up && H > 1 ? (float)(p.up_hs - 1) / (float)(H - 1) : 0.f;
   const float usx = up && W > 1 ? (float)(p.up_ws - 1) / (float)(W - 1) : 0.f;
   if (up) xin = p.x + (size_t)n * p.up_hs * p.up_ws * Cin;
-  float4 hv[4][2];     // plain: hv[0]; up: the 4 corners
-  float4 ha[2];        // position-table add (up mode with tables)
-  float hw[4];         // corner weights
-  bool h_in = false;   // the halo pixel lies inside the image
-  auto halo_load = [&](int cc, int i) {
+  struct HaloItem {
+    float4 hv[4][2];     // plain: hv[0]; up: the 4 corners
+    float4 ha[2];        // position-table add (up mode with tables)
+    float hw[4];         // corner weights
+    bool in;             // the halo pixel lies inside the image
+  };
+  HaloItem it0;
+  it0.in = false;
+  auto halo_load_it = [&](HaloItem& it, int cc, int i) {
+    float4 (&hv)[4][2] = it.hv; float4 (&ha)[2] = it.ha; float (&hw)[4] = it.hw; bool& h_in = it.in;
     const int id = tid + i * 512;
     const int hr = id >> 3, ch = id & 7;
     const int hy = hr / HW_, hx = hr - hy * HW_;
@@ -99,7 +104,8 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
       }
     }
   };
-  auto halo_store = [&](char* dst, int i) {
+  auto halo_store_it = [&](HaloItem& it, char* dst, int i) {
+    float4 (&hv)[4][2] = it.hv; float4 (&ha)[2] = it.ha; float (&hw)[4] = it.hw; const bool h_in = it.in;
     const int id = tid + i * 512;
     if (id >= HCH) return;
     const int hr = id >> 3, ch = id & 7;
@@ -133,6 +139,8 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
     u.w = (uint32_t)f2t<T>(v[6]) | ((uint32_t)f2t<T>(v[7]) << 16);
     *(uint4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = u;
   };
+  auto halo_load = [&](int cc, int i) { halo_load_it(it0, cc, i); };
+  auto halo_store = [&](char* dst, int i) { halo_store_it(it0, dst, i); };
   // ---- weight tile (chunk cc, tap) by LDS-DMA, swizzle on the source address
   auto stage_w = [&](int cc, int tap, char* dst) {
     for (int pc = wave; pc < PB; pc += 8) {
@@ -161,6 +169,54 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   }
 
   const int nchunks = Cin / 64;
+  if constexpr (PP == 2) {
+    // Narrow variant (Cout <= 32: output_conv2[0], 128 -> 32 at full resolution with the resize fused): the MFMA work
+    // per tap is 4 instructions per wave, so the per-tap DMA wait + barrier of the loops below IS the run time
+    // (20 us per block, measured).  Here a chunk's whole halo and all 9 weight tiles (36 KiB) are staged up front and
+    // the 36 MFMA steps run without a barrier; the halo comes in two batches of three items per thread (12 KiB of
+    // loads in flight per wave), i.e. two memory latencies per chunk instead of nine: 740 -> 650 us for the fused
+    // 296 -> 518 resize + conv at 8 views.  What remains is L2 bandwidth: the 4-corner gather reads every source value
+    // ~5 times (5.6 GB per launch).  Staging the ~12 x 12 source patch in LDS by DMA and blending from LDS was tried
+    // and was slower (spills at 256 VGPRs); left for a dedicated kernel.
+    static_assert(PP != 2 || (TM == 1 && TN == 1 && WM == 8), "narrow variant: 32 px x 32 ch per wave");
+    HaloItem it1, it2;
+    it1.in = it2.in = false;
+    for (int cc = 0; cc < nchunks; ++cc) {
+      if (cc) __syncthreads();  // everybody finished reading the previous chunk's halo and weights
+      for (int pc = wave; pc < 36; pc += 8) {  // weights [tap][cout 0..31][64 cin]: 4 pieces per tap
+        const int tap = pc >> 2, r = (pc & 3) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(r);
+        int co = n0 + r;
+        co = co < Cout ? co : Cout - 1;
+        __builtin_amdgcn_global_load_lds((glb_vp)(Wt + (size_t)co * K + tap * Cin + cc * 64 + c * 8), (lds_vp)(bbuf + pc * 1024), 16, 0, 0);
+      }
+#pragma unroll 1
+      for (int i = 0; i < HPT; i += 3) {
+        halo_load_it(it0, cc, i);
+        if (i + 1 < HPT) halo_load_it(it1, cc, i + 1);
+        if (i + 2 < HPT) halo_load_it(it2, cc, i + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // register loads are consumed only after a full drain (DMA pending)
+        halo_store_it(it0, hbuf, i);
+        if (i + 1 < HPT) halo_store_it(it1, hbuf, i + 1);
+        if (i + 2 < HPT) halo_store_it(it2, hbuf, i + 2);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = (tap / 3) * HW_ + (tap % 3);
+        const int hr = hbase[0] + toff;
+        const int row = tap * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int ch = 2 * ks + (lane >> 5);
+          const s16x8 a = *(const s16x8*)(hbuf + hr * 128 + ((ch ^ swz(hr)) << 4));
+          const s16x8 b = *(const s16x8*)(bbuf + row * 128 + ((ch ^ swz(row & 31)) << 4));
+          acc[0][0] = mfma32<T>(b, a, acc[0][0]);
+        }
+      }
+    }
+  } else {
   static_assert(HPT <= 7, "one halo item per tap, stored one tap later");
 #pragma unroll 1
   for (int i = 0; i < HPT; ++i) {
@@ -271,6 +327,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   }
 
   }  // lock-step loop
+  }  // not narrow
   // ---- epilogue: lane = pixel (lane&31) of tile i, regs 4g..4g+3 <-> channels 8g + 4h + {0..3}
   const int h4 = (lane >> 5) * 4;
 #pragma unroll
@@ -310,7 +367,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
 template <int T, int WM, int WN, int TM, int TN, int PP = 0>
 hipError_t launch_cfg(const WmConvArgs& a, hipStream_t s) {
   constexpr int BN = WN * TN * 32;
-  const size_t shm = 2 * HALO_BYTES + 2 * BN * 128;
+  const size_t shm = PP == 2 ? HALO_BYTES + 9 * 32 * 128 : 2 * HALO_BYTES + 2 * BN * 128;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, WM, WN, TM, TN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -335,7 +392,8 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   if (bn >= 256) return wm_tuning[WM_TUNE_CONV_PP] == 1 ? launch_cfg<T, 2, 4, 4, 2, 1>(a, s) : launch_cfg<T, 2, 4, 4, 2, 0>(a, s);  // 256 px x 256 ch
   if (bn >= 128) return launch_cfg<T, 4, 2, 2, 2>(a, s);   // 256 px x 128 ch
   if (bn >= 64) return launch_cfg<T, 4, 2, 2, 1>(a, s);    // 256 px x 64 ch
-  return launch_cfg<T, 8, 1, 1, 1>(a, s);                  // 256 px x 32 ch
+  if (wm_tuning[WM_TUNE_CONV_PP] == 3) return launch_cfg<T, 8, 1, 1, 1>(a, s);  // per-tap loop (A/B)
+  return launch_cfg<T, 8, 1, 1, 1, 2>(a, s);               // 256 px x 32 ch, narrow variant
 }
 
 }  // namespace
