@@ -442,6 +442,72 @@ hipError_t wm_launch_add(const float* a, const float* b, float* out, size_t n, h
   return hipGetLastError();
 }
 
+// depth_to_world_coords_points (src/models/utils/geometry.py:5-89; callers infer.py:303, app.py:151): per pixel
+//   cam = ((u - cx) z / fx, (v - cy) z / fy, z),  world = R cam + t  (extrinsic = camera-to-world),  mask = z > eps.
+// HBM-bound: 4 B read, 12 + 12 + 1 B written per pixel.  Same operation order as the reference's fp32 expressions
+// ((u - cx) * z, then / fx; no contraction of the mul into the divide).
+// VEC = 4: one thread owns 4 consecutive pixels -> one 16-B depth load, three 16-B stores per output tensor.
+template <int VEC>
+__global__ __launch_bounds__(256) void depth_to_world_kernel(const float* __restrict__ depth, const float* __restrict__ ext,
+                                                             const float* __restrict__ intr, float* __restrict__ world,
+                                                             float* __restrict__ cam, unsigned char* __restrict__ mask, int B,
+                                                             int H, int W, float eps) {
+  const size_t hw = (size_t)H * W, total = (size_t)B * hw / VEC;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float zz[VEC], cw[3 * VEC], cc[3 * VEC];
+    if constexpr (VEC == 4) {
+      const float4 d4 = *(const float4*)(depth + 4 * i);
+      zz[0] = d4.x; zz[1] = d4.y; zz[2] = d4.z; zz[3] = d4.w;
+    } else {
+      zz[0] = depth[i];
+    }
+    unsigned int mbits = 0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const size_t px = VEC * i + e;
+      const int b = (int)(px / hw);
+      const size_t r = px - (size_t)b * hw;
+      const int v = (int)(r / W), u = (int)(r - (size_t)v * W);
+      const float* K = intr + b * 9;
+      const float* E = ext + b * 16;
+      const float z = zz[e];
+      const float x = __fdiv_rn(__fmul_rn((float)u - K[2], z), K[0]);
+      const float y = __fdiv_rn(__fmul_rn((float)v - K[5], z), K[4]);
+      cc[3 * e] = x; cc[3 * e + 1] = y; cc[3 * e + 2] = z;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cw[3 * e + j] = E[4 * j] * x + E[4 * j + 1] * y + E[4 * j + 2] * z + E[4 * j + 3];
+      mbits |= (z > eps ? 1u : 0u) << (8 * e);
+    }
+    if constexpr (VEC == 4) {
+      if (cam) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *(float4*)(cam + 12 * i + 4 * q) = make_float4(cc[4 * q], cc[4 * q + 1], cc[4 * q + 2], cc[4 * q + 3]);
+      }
+      if (world) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *(float4*)(world + 12 * i + 4 * q) = make_float4(cw[4 * q], cw[4 * q + 1], cw[4 * q + 2], cw[4 * q + 3]);
+      }
+      if (mask) *(unsigned int*)(mask + 4 * i) = mbits;
+    } else {
+      if (cam) { cam[3 * i] = cc[0]; cam[3 * i + 1] = cc[1]; cam[3 * i + 2] = cc[2]; }
+      if (world) { world[3 * i] = cw[0]; world[3 * i + 1] = cw[1]; world[3 * i + 2] = cw[2]; }
+      if (mask) mask[i] = (unsigned char)mbits;
+    }
+  }
+}
+
+hipError_t wm_launch_depth_to_world(const float* depth, const float* ext, const float* intr, float* world, float* cam,
+                                    unsigned char* mask, int B, int H, int W, float eps, hipStream_t s) {
+  const size_t total = (size_t)B * H * W;
+  if (!total) return hipSuccess;
+  const bool al = (((size_t)depth | (size_t)world | (size_t)cam) & 15) == 0 && ((size_t)mask & 3) == 0;
+  if (total % 4 == 0 && al)
+    hipLaunchKernelGGL(depth_to_world_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, s, depth, ext, intr, world, cam, mask, B, H, W, eps);
+  else
+    hipLaunchKernelGGL(depth_to_world_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, depth, ext, intr, world, cam, mask, B, H, W, eps);
+  return hipGetLastError();
+}
+
 hipError_t wm_launch_dpt_tail(const float* y32, const float* w, const float* b, float* attr, float* conf, size_t npix,
                               int C, int act, hipStream_t s) {
   if (C < 2 || C > 4) return hipErrorInvalidValue;

@@ -94,6 +94,8 @@ hipError_t wm_launch_bilinear(const float* in, float* out, int N, int Hi, int Wi
 // out = a + b (f32), n elements
 hipError_t wm_launch_add(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 // DPT tail: y32 f32 NHWC [n][H][W][32] (pre-ReLU) -> relu -> 1x1 (32->C) -> activation; writes attr [n][H][W][C-1], conf [n][H][W]
+hipError_t wm_launch_depth_to_world(const float* depth, const float* ext, const float* intr, float* world, float* cam,
+                                    unsigned char* mask, int B, int H, int W, float eps, hipStream_t s);
 hipError_t wm_launch_dpt_tail(const float* y32, const float* w, const float* b, float* attr, float* conf,
                               size_t npix, int C, int act, hipStream_t s);
 enum { WM_ACT_INV_LOG = 0, WM_ACT_EXP = 1, WM_ACT_NORM = 2 };

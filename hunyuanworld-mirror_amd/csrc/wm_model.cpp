@@ -1288,6 +1288,11 @@ extern "C" wm_status wm_op_conv3x3_up(int dtype, const float* x, const void* w16
   if (getenv("WM_DBG_LATE")) a.relu_out = 7;
   return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
+extern "C" wm_status wm_depth_to_world(const float* depth, const float* extrinsic, const float* intrinsic, float* world, float* cam,
+                                       unsigned char* mask, int B, int H, int W, float eps, void* stream) {
+  if (!depth || !extrinsic || !intrinsic || B < 0 || H < 0 || W < 0) return WM_ERR_INVALID;
+  return wm_launch_depth_to_world(depth, extrinsic, intrinsic, world, cam, mask, B, H, W, eps, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
 extern "C" wm_status wm_op_bilinear(const float* in, float* out, int N, int Hi, int Wi, int Ho, int Wo, int C, void* stream) {
   return wm_launch_bilinear(in, out, N, Hi, Wi, Ho, Wo, C, nullptr, nullptr, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }

@@ -138,6 +138,13 @@ wm_status wm_op_bilinear(const float* in, float* out, int N, int Hi, int Wi, int
 wm_status wm_op_linear_f32(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int ldx, int pre_act,
                            int post_act, void* stream);
 /* host helper: fp32 -> 16-bit (round to nearest even), for building test operands */
+/* ---- post-path geometry (the step right after the path in infer.py:303 / app.py:151) ----
+ * depth_to_world_coords_points (src/models/utils/geometry.py:57-89): depth [B][H][W] f32, extrinsic [B][4][4]
+ * camera-to-world, intrinsic [B][3][3] -> world [B][H][W][3], cam [B][H][W][3], mask [B][H][W] (u8, depth > eps).
+ * Any of world / cam / mask may be NULL.  Device pointers, stream-ordered. */
+wm_status wm_depth_to_world(const float* depth, const float* extrinsic, const float* intrinsic, float* world, float* cam,
+                            unsigned char* mask, int B, int H, int W, float eps, void* stream);
+
 /* Process-wide kernel-selection override for tests and A/B tools (no reference counterpart).  key: "gemm_cfg"
  * (tile config id), "gemm_pp" (0/1 ping-pong GEMM), "gemm_mfma16" (0/1/2), "attn_qb" (attention variant);
  * value -1 restores the default.  Returns 0, or -1 for an unknown key. */

@@ -16,14 +16,14 @@ def ref_check(qb, H=4, M=2752):
     a = torch.softmax((q.float() @ k.float().transpose(-1, -2)) * math.log(2.0), -1) @ v.float()
     got = o.view(torch.bfloat16).float().reshape(M, H, 64).transpose(0, 1)
     return float((got - a).norm() / a.norm())
-for qb in (3, 13): print("relerr qb", qb, ref_check(qb), ref_check(qb, 2, 1000), flush=True)
+for qb in (3,): print("relerr qb", qb, ref_check(qb), ref_check(qb, 2, 1000), flush=True)
 for name, H, M, Ls in [("frame_8x1376", 16, 8 * 1376, 1376), ("global_8v", 16, 8 * 1376, 8 * 1376), ("global_32v", 16, 32 * 1376, 32 * 1376)]:
     q = (torch.randn(H, M, 64, device=dev) * 0.125).to(torch.bfloat16); k = torch.randn(H, M, 64, device=dev).to(torch.bfloat16)
     v = torch.randn(H, M, 64, device=dev).to(torch.bfloat16); o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
     fl = 4.0 * M * Ls * 64 * H
     res = {}
     for rep in range(2):
-        for label, qb in (("dma3", 3), ("ring3", 13)):
+        for label, qb in (("base", 3), ("noVALU", 21), ("quarterMFMA", 22), ("noStream", 23)):
             tune("attn_qb", qb)
             for _ in range(2): L.wm_op_attention(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, s)
             torch.cuda.synchronize()
