@@ -203,11 +203,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
         }
         if (do_rope) {
           const int rr = row_ok ? row : 0;
-          const int t = rr % q.tokens_per_view;
+          // row / tokens_per_view and idx / grid_w by float multiplication (exact here: rows < 2^20, quotients < 2^11,
+          // the +0.5 keeps the product > 1e-4 away from an integer) — two runtime integer divisions were ~80 VALU per row
+          const int t = rr - (int)(((float)rr + 0.5f) * q.inv_tpv) * q.tokens_per_view;
           int py = 0, px = 0;
           if (t >= q.patch_start) {
             const int idx = t - q.patch_start;
-            py = idx / q.grid_w + 1;
+            py = (int)(((float)idx + 0.5f) * q.inv_gw) + 1;
             px = idx - (py - 1) * q.grid_w + 1;
           }
 #pragma unroll
@@ -411,11 +413,11 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
       }
       if (do_rope) {
         const int rr = row_ok ? row : 0;
-        const int t = rr % q.tokens_per_view;
+        const int t = rr - (int)(((float)rr + 0.5f) * q.inv_tpv) * q.tokens_per_view;  // see gemm_nt_kernel
         int py = 0, px = 0;
         if (t >= q.patch_start) {
           const int idx = t - q.patch_start;
-          py = idx / q.grid_w + 1;
+          py = (int)(((float)idx + 0.5f) * q.inv_gw) + 1;
           px = idx - (py - 1) * q.grid_w + 1;
         }
 #pragma unroll
@@ -955,5 +957,12 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
   if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
   const int cfg = pick_cfg(a);
+  if (a.epi == WM_EPI_QKV) {
+    if (a.qkv.tokens_per_view <= 0 || a.qkv.grid_w <= 0 || a.M >= (1 << 20) || a.qkv.tokens_per_view >= (1 << 16)) return hipErrorInvalidValue;
+    WmGemmArgs b = a;
+    b.qkv.inv_tpv = 1.0f / (float)a.qkv.tokens_per_view;
+    b.qkv.inv_gw = 1.0f / (float)a.qkv.grid_w;
+    return b.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(b, cfg, s) : launch_T<WM_T_F16>(b, cfg, s);
+  }
   return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, cfg, s) : launch_T<WM_T_F16>(a, cfg, s);
 }

@@ -22,6 +22,7 @@ struct WmQkvArgs {
   const float* rope_cos; const float* rope_sin;                                  // [max_pos][16], null = no rope
   int M, H, head_stride;   // head_stride = rows per head in the outputs
   int tokens_per_view, patch_start, grid_w;  // position of token t: special (0,0) or (y+1, x+1)
+  float inv_tpv, inv_gw;                     // 1/tokens_per_view, 1/grid_w (filled by wm_launch_gemm: the epilogue divides by multiplication)
   float q_scale; int dtype;
 };
 
