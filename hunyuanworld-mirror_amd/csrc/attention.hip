@@ -53,7 +53,7 @@ __device__ __forceinline__ float ceil_t16(float x) {
   return y;
 }
 
-template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1, int STG = 1>
+template <int T, int NW, int QB, int MINW, int LZ = 1, int STG = 1>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int QT = NW * 32 * QB;  // query rows per block; each wave owns QB blocks of 32 rows
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
     const char* vt = kt + TILE_B;
     if (STG == 2) {
       if (t + 2 < t1) dma_tile((t - t0 + 2) % 3);  // the buffer of tile t-1: everybody passed the barrier that ended it
-    } else if (t + 1 < t1 && DBG != 3) {
+    } else if (t + 1 < t1) {
       if (STG) dma_tile(cur ^ 1);  // everybody passed the barrier that ended tile t-1: the other buffer is free
       else load_tile(t + 1);       // global -> regs, hidden under the MFMA phase
     }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
         const s16x8 kf = *(const s16x8*)(kt + key * 128 + (((2 * ks + h) ^ ((key >> 1) & 7)) << 4));
 #pragma unroll
         for (int b = 0; b < QB; ++b)
-          if (DBG != 2 || ks == 0) st[b][k2] = mfma32<T>(kf, qf[b][ks], st[b][k2]);
+          st[b][k2] = mfma32<T>(kf, qf[b][ks], st[b][k2]);
       }
     }
     // ---- tail mask (wave-uniform branch; only the last tile of a segment)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            pv[k2][r] = DBG == 1 ? st[b][k2][r] : __builtin_amdgcn_exp2f(st[b][k2][r]);
+            pv[k2][r] = __builtin_amdgcn_exp2f(st[b][k2][r]);
             sum += pv[k2][r];
           }
       }
@@ -319,17 +319,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
           vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
 #pragma unroll
           for (int b = 0; b < QB; ++b)
-            if (DBG != 2 || (k2 == 0 && s2 == 0)) ot[b][d] = mfma32<T>(vf, pf[b][k2][s2], ot[b][d]);
+            ot[b][d] = mfma32<T>(vf, pf[b][k2][s2], ot[b][d]);
         }
       }
-    if (DBG != 3) {
-      if (STG == 2) {  // tile t+1 must have landed; tile t+2 (if any) may stay in flight
-        if (t + 2 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (t + 1 < t1) store_tile(cur ^ 1);
-      __syncthreads();
-    }
+    if (STG == 2) {  // tile t+1 must have landed; tile t+2 (if any) may stay in flight
+      if (t + 2 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (t + 1 < t1) store_tile(cur ^ 1);
+    __syncthreads();
   }
 
   if (nsplit > 1) {  // unnormalised partial: O^T (fp32), running max and sum; the combine pass finishes the softmax
@@ -692,7 +690,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p) {
   *(uint2*)((u16*)p.O + (row * p.H + head) * 64 + d4 * 4) = u;
 }
 
-template <int T, int NW, int QB, int MINW, int DBG = 0, int LZ = 1, int STG = 1>
+template <int T, int NW, int QB, int MINW, int LZ = 1, int STG = 1>
 hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
   constexpr int QT = NW * 32 * QB;
   WmAttnArgs a = a_in;
@@ -716,7 +714,7 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
     a.kv_splits = best;
   }
   dim3 grid(tiles_per_seq * nseq * a.H * a.kv_splits), block(NW * 64);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, DBG, LZ, STG>), grid, block, 0, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, LZ, STG>), grid, block, 0, s, a);
   if (a.kv_splits > 1) {
     const size_t nthr = (size_t)a.q_rows * a.H * 16;
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
@@ -732,17 +730,11 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
   const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
   const int qb = forced ? forced : 3;  // 64 rows per wave, 2 waves/SIMD, lazy max: fastest on every shape of the path (tools/attn_exp.py)
-#ifdef WM_ATTN_DEBUG  // timing experiments only (wrong results): 21 no softmax VALU, 22 a quarter of the MFMAs, 23 no K/V streaming, 24 one wave per SIMD
-  if (qb == 21) return launch<WM_T_BF16, 4, 2, 2, 1>(a, s);
-  if (qb == 22) return launch<WM_T_BF16, 4, 2, 2, 2>(a, s);
-  if (qb == 23) return launch<WM_T_BF16, 4, 2, 2, 3>(a, s);
-  if (qb == 24) return launch<WM_T_BF16, 4, 2, 1, 0>(a, s);
-#endif
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);
-  if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0, 0>(a, s);  // eager max (A/B)
-  if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0, 0>(a, s);
-  if (qb == 13) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0, 1, 2>(a, s) : launch<WM_T_F16, 4, 2, 2, 0, 1, 2>(a, s);  // 3-deep DMA ring
-  if (qb == 12) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0, 1, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0, 1, 0>(a, s);  // register staging (A/B)
+  if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0>(a, s);  // eager max (A/B)
+  if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0>(a, s);
+  if (qb == 13) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 1, 2>(a, s) : launch<WM_T_F16, 4, 2, 2, 1, 2>(a, s);  // 3-deep DMA ring
+  if (qb == 12) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 1, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 1, 0>(a, s);  // register staging (A/B)
   if (qb == 2) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 1>(a, s) : launch<WM_T_F16, 4, 2, 1>(a, s);
   if (qb == 3) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s) : launch<WM_T_F16, 4, 2, 2>(a, s);
   if (qb == 4) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3>(a, s) : launch<WM_T_F16, 4, 1, 3>(a, s);

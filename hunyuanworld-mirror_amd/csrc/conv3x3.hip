@@ -26,7 +26,7 @@ constexpr int HPT = (HCH + 511) / 512;      // chunks per thread (6)
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int T, int WM, int WN, int TM, int TN, int PP = 0>
+template <int T, int WM, int WN, int TM, int TN, int NARROW = 0>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   constexpr int BN = WN * TN * 32;
   constexpr int B_BYTES = BN * 128;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   static_assert(WM * WN == 8 && WM * TM * 32 == 256, "8 waves x 256 pixels");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 halo][2 B]
   char* hbuf = smem;
-  char* bbuf = smem + (PP == 2 ? 1 : 2) * HALO_BYTES;  // PP 2 (narrow): one halo buffer, then all 9 taps' weights
+  char* bbuf = smem + (NARROW ? 1 : 2) * HALO_BYTES;  // NARROW: one halo buffer, then all 9 taps' weights
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   }
 
   const int nchunks = Cin / 64;
-  if constexpr (PP == 2) {
+  if constexpr (NARROW) {
     // Narrow variant (Cout <= 32: output_conv2[0], 128 -> 32 at full resolution with the resize fused): the MFMA work
     // per tap is 4 instructions per wave, so the per-tap DMA wait + barrier of the loops below IS the run time
     // (20 us per block, measured).  Here a chunk's whole halo and all 9 weight tiles (36 KiB) are staged up front and
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
     // 296 -> 518 resize + conv at 8 views.  What remains is L2 bandwidth: the 4-corner gather reads every source value
     // ~5 times (5.6 GB per launch).  Staging the ~12 x 12 source patch in LDS by DMA and blending from LDS was tried
     // and was slower (spills at 256 VGPRs); left for a dedicated kernel.
-    static_assert(PP != 2 || (TM == 1 && TN == 1 && WM == 8), "narrow variant: 32 px x 32 ch per wave");
+    static_assert(!NARROW || (TM == 1 && TN == 1 && WM == 8), "narrow variant: 32 px x 32 ch per wave");
     HaloItem it1, it2;
     it1.in = it2.in = false;
     for (int cc = 0; cc < nchunks; ++cc) {
@@ -225,67 +225,6 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
     halo_store(hbuf, i);
   }
   stage_w(0, 0, bbuf);
-  if constexpr (PP) {
-    // Ping-pong main loop (same idea as gemm_pp_kernel): the (chunk, tap) step is two phases of 2 k-slices = 16 MFMAs;
-    // every phase is {load stage: ds_read the phase's fragments | barrier | MFMA stage | barrier} and waves 4-7 run
-    // one barrier behind waves 0-3, so on every SIMD one wave multiplies while its partner reads LDS / issues the
-    // next weights' DMA / stages a halo item.  Weights(kt+1) are issued in phase 0 and drained by every wave
-    // (vmcnt(0), which also covers the halo item's register loads — see the ordering rule above) in phase 1, before
-    // a barrier all readers pass; own ds_reads are retired (lgkmcnt(0)) before the barrier that ends a load stage.
-    static_assert(!PP || (TM == 4 && TN == 2), "ping-pong loop is written for the 128 px x 64 ch wave tile");
-    const int grp = wave >> 2;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int kt = 0;
-    for (int cc = 0; cc < nchunks; ++cc) {
-      const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
-      for (int tap = 0; tap < 9; ++tap, ++kt) {
-        const char* tB = bbuf + (kt & 1) * B_BYTES;
-        const int toff = (tap / 3) * HW_ + (tap % 3);
-        const bool last = cc + 1 == nchunks && tap == 8;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-          s16x8 a[2][TM], b[2][TN];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int ch = 2 * (2 * ph + q) + (lane >> 5);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const int row = (wn * TN + j) * 32 + (lane & 31);
-              b[q][j] = *(const s16x8*)(tB + row * 128 + ((ch ^ swz(row)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-              const int hr = hbase[i] + toff;
-              a[q][i] = *(const s16x8*)(hcur + hr * 128 + ((ch ^ swz(hr)) << 4));
-            }
-          }
-          if (ph == 0) {
-            if (tap >= 1 && tap <= HPT && cc + 1 < nchunks) halo_store(hbuf + ((cc + 1) & 1) * HALO_BYTES, tap - 1);
-            if (!last) stage_w(tap == 8 ? cc + 1 : cc, tap == 8 ? 0 : tap + 1, bbuf + ((kt + 1) & 1) * B_BYTES);
-            if (tap < HPT && cc + 1 < nchunks) halo_load(cc + 1, tap);
-          } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(b[q][j], a[q][i], acc[i][j]);
-          __builtin_amdgcn_s_setprio(0);
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_barrier();
-        }
-      }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-  } else {
   int kt = 0;
   for (int cc = 0; cc < nchunks; ++cc) {
     const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
@@ -326,7 +265,6 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
     }
   }
 
-  }  // lock-step loop
   }  // not narrow
   // ---- epilogue: lane = pixel (lane&31) of tile i, regs 4g..4g+3 <-> channels 8g + 4h + {0..3}
   const int h4 = (lane >> 5) * 4;
@@ -364,17 +302,17 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   }
 }
 
-template <int T, int WM, int WN, int TM, int TN, int PP = 0>
+template <int T, int WM, int WN, int TM, int TN, int NARROW = 0>
 hipError_t launch_cfg(const WmConvArgs& a, hipStream_t s) {
   constexpr int BN = WN * TN * 32;
-  const size_t shm = PP == 2 ? HALO_BYTES + 9 * 32 * 128 : 2 * HALO_BYTES + 2 * BN * 128;
+  const size_t shm = NARROW ? HALO_BYTES + 9 * 32 * 128 : 2 * HALO_BYTES + 2 * BN * 128;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, WM, WN, TM, TN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)conv3x3_kernel<T, WM, WN, TM, TN, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
   const int nblk = a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP) * ((a.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, TM, TN, PP>), dim3(nblk), dim3(512), shm, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<T, WM, WN, TM, TN, NARROW>), dim3(nblk), dim3(512), shm, s, a);
   return hipGetLastError();
 }
 
@@ -389,11 +327,11 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   int bn = a.Cout > 128 ? 256 : a.Cout > 64 ? 128 : a.Cout > 32 ? 64 : 32;
   while (bn > 64 && 2 * ptiles * ((a.Cout + bn - 1) / bn) < ncu) bn >>= 1;
   if (wm_tuning[WM_TUNE_CONV_BN] > 0) bn = wm_tuning[WM_TUNE_CONV_BN];
-  if (bn >= 256) return wm_tuning[WM_TUNE_CONV_PP] == 1 ? launch_cfg<T, 2, 4, 4, 2, 1>(a, s) : launch_cfg<T, 2, 4, 4, 2, 0>(a, s);  // 256 px x 256 ch
+  if (bn >= 256) return launch_cfg<T, 2, 4, 4, 2>(a, s);   // 256 px x 256 ch (a two-group ping-pong main loop was tried here: bit-identical, no faster)
   if (bn >= 128) return launch_cfg<T, 4, 2, 2, 2>(a, s);   // 256 px x 128 ch
   if (bn >= 64) return launch_cfg<T, 4, 2, 2, 1>(a, s);    // 256 px x 64 ch
-  if (wm_tuning[WM_TUNE_CONV_PP] == 3) return launch_cfg<T, 8, 1, 1, 1>(a, s);  // per-tap loop (A/B)
-  return launch_cfg<T, 8, 1, 1, 1, 2>(a, s);               // 256 px x 32 ch, narrow variant
+  if (wm_tuning[WM_TUNE_CONV_NARROW] == 0) return launch_cfg<T, 8, 1, 1, 1>(a, s);  // per-tap loop (A/B)
+  return launch_cfg<T, 8, 1, 1, 1, 1>(a, s);               // 256 px x 32 ch, narrow variant
 }
 
 }  // namespace

@@ -13,8 +13,8 @@ b = torch.randn(Cout, device=dev); y = torch.empty(N, Hi, Wi, Cout, device=dev)
 ax = torch.randn(Wi, Cin // 2, device=dev); ay = torch.randn(Hi, Cin // 2, device=dev)
 res = {}; outs = {}
 for rep in range(2):
-    for label, pp in (("per_tap", 3), ("narrow", -1)):
-        tune("conv_pp", pp)
+    for label, pp in (("per_tap", 0), ("narrow", -1)):
+        tune("conv_narrow", pp)
         for _ in range(2): L.wm_op_conv3x3_up(1, p(x), p(w16), p(b), p(y), N, Hs, Ws, Hi, Wi, Cin, Cout, p(ax), p(ay), s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
