@@ -18,6 +18,7 @@
 #include "wm_kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
 
@@ -693,10 +694,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const WmGemmArgs p) {
 //   end of phase 0:  B1(t) landed        <=> at most  2 + 8[t+1 < nk]
 //   end of phase 1:  A1(t) landed        <=> at most  8[t+1 < nk] + 4[t+2 < nk]
 // RAW/WAR argument as for v1 (wait, then a barrier every reader passes; own reads retired before the stage's barrier).
-template <int T, int EPI, int PRIO, int DBG = 0>
+// QI = 3 (192-row tile: wave tile 96 x 64, quadrants of 3 sub-tiles): the A regions have 12 pieces, so waves 0-3 carry
+// two per region and waves 4-7 one; the counted waits then differ per wave half (R_A0B0 = nA + 2, R_B1 = 2, R_A1 = nA,
+// nA = 2 | 1  ->  12 / 10 / 12 / 8 / 4 / 2  |  9 / 7 / 9 / 6 / 3 / 1), selected by a wave-uniform branch.
+template <int T, int EPI, int PRIO, int DBG = 0, int QI = 4>
 __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
-  constexpr int SM = 8, SN = 4, BM = 256, BN = 256;
-  constexpr int A_BYTES = BM * 128, STAGE = 2 * A_BYTES;
+  constexpr int SM = 2 * QI, SN = 4, WROWS = SM * 16, BM = 2 * WROWS, BN = 256;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int APC = QI * 2;  // 8-row pieces per (wave row half, quadrant): 8 or 6
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -704,17 +709,23 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
   const int l15 = lane & 15, lq = lane >> 4;
+  const bool two = QI == 4 || wave < 4;  // this wave carries two A pieces per region (wave-uniform)
 
-  // this wave's 8 DMA pieces per K-tile, in issue order: A0 A0 B0 B0 | B1 B1 | A1 A1
+  // this wave's DMA pieces per K-tile, in issue order: A0 A0 B0 B0 | B1 B1 | A1 A1 (the second A piece only if `two`)
   const u16* gp[8];
   int loff[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int cl = 2 * wave + (i & 1);              // index inside the 16-piece region
     const bool isA = i < 2 || i >= 6;
     const int half = (i >= 4) ? 1 : 0;              // A1 / B1
-    const int pl = isA ? (cl < 8 ? cl : cl + 8) + 8 * half            // rows wr'*128 + 64 qm + ...
-                       : (cl >> 2) * 8 + (cl & 3) + 4 * half;         // cols wc'*64 + 32 qn + ...
+    int pl;
+    if (isA) {
+      const int cl = QI == 4 ? 2 * wave + (i & 1) : (wave < 4 ? 2 * wave + (i & 1) : 8 + (wave - 4));  // index in the 2*APC-piece region
+      pl = (cl < APC ? cl : cl - APC + 2 * APC) + APC * half;   // rows wr' * WROWS + 8 * APC * qm + ...
+    } else {
+      const int cl = 2 * wave + (i & 1);
+      pl = (cl >> 2) * 8 + (cl & 3) + 4 * half;                 // cols wc' * 64 + 32 qn + ...
+    }
     const int r = pl * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int gr = (DBG == 4 ? 0 : (isA ? m0 : n0)) + r;
@@ -726,24 +737,29 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   auto dma = [&](int buf, int i0, int i1) {
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
+      if ((i == 1 || i == 7) && !two) continue;  // wave-uniform
       __builtin_amdgcn_global_load_lds((glb_vp)gp[i], (lds_vp)(smem + buf * STAGE + loff[i]), 16, 0, 0);
       gp[i] += 64;
     }
   };
+  auto wait2 = [&](auto n2c, auto n1c) {  // counted wait: immediates for the two-piece / one-piece wave halves
+    if (two) wait_vmcnt<decltype(n2c)::value>(); else wait_vmcnt<decltype(n1c)::value>();
+  };
+#define WM_W2(a_, b_) wait2(std::integral_constant<int, a_>{}, std::integral_constant<int, b_>{})
   const int sw = (l15 >> 1) & 7;
   const int foff0 = l15 * 128 + ((lq ^ sw) << 4), foff1 = l15 * 128 + (((4 + lq) ^ sw) << 4);
-  const int a_base = wr * 128 * 128, b_base = A_BYTES + wc * 64 * 128;
+  const int a_base = wr * WROWS * 128, b_base = A_BYTES + wc * 64 * 128;
 
   f32x4 acc[SM][SN];
 #pragma unroll
   for (int i = 0; i < SM; ++i)
 #pragma unroll
     for (int j = 0; j < SN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  s16x8 a[4][2], b0[2][2], b1[2][2];
+  s16x8 a[QI][2], b0[2][2], b1[2][2];
 
   const int nk = p.K / 64;
   dma(0, 0, 8);
-  if (nk > 1) { dma(1, 0, 8); wait_vmcnt<12>(); } else wait_vmcnt<4>();
+  if (nk > 1) { dma(1, 0, 8); WM_W2(12, 9); } else WM_W2(4, 3);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
@@ -770,16 +786,16 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
       b0[j][1] = *(const s16x8*)(tile + b_base + j * 2048 + foff1);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < QI; ++i) {
       a[i][0] = *(const s16x8*)(tile + a_base + i * 2048 + foff0);
       a[i][1] = *(const s16x8*)(tile + a_base + i * 2048 + foff1);
     }
-    if (n1) wait_vmcnt<10>(); else wait_vmcnt<2>();
+    if (n1) WM_W2(10, 7); else WM_W2(2, 1);
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < QI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<T>(b0[j][kh], a[i][kh], acc[i][j]);
     mfma_end();
@@ -789,55 +805,57 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
       b1[j][0] = *(const s16x8*)(tile + b_base + (2 + j) * 2048 + foff0);
       b1[j][1] = *(const s16x8*)(tile + b_base + (2 + j) * 2048 + foff1);
     }
-    if (n2) { dma(buf, 0, 4); wait_vmcnt<12>(); } else if (n1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    if (n2) { dma(buf, 0, 4); WM_W2(12, 9); } else if (n1) WM_W2(8, 6); else wait_vmcnt<0>();
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < QI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16<T>(b1[j][kh], a[i][kh], acc[i][2 + j]);
     mfma_end();
     // ---- phase 2: quadrant (1,1); refill B1
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a[i][0] = *(const s16x8*)(tile + a_base + (4 + i) * 2048 + foff0);
-      a[i][1] = *(const s16x8*)(tile + a_base + (4 + i) * 2048 + foff1);
+    for (int i = 0; i < QI; ++i) {
+      a[i][0] = *(const s16x8*)(tile + a_base + (QI + i) * 2048 + foff0);
+      a[i][1] = *(const s16x8*)(tile + a_base + (QI + i) * 2048 + foff1);
     }
     if (n2) dma(buf, 4, 6);
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < QI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16<T>(b1[j][kh], a[i][kh], acc[4 + i][2 + j]);
+        for (int j = 0; j < 2; ++j) acc[QI + i][2 + j] = mfma16<T>(b1[j][kh], a[i][kh], acc[QI + i][2 + j]);
     mfma_end();
     // ---- phase 3: quadrant (1,0) from registers; refill A1; next K-tile's {A0,B0} must have landed
-    if (n2) { dma(buf, 6, 8); wait_vmcnt<12>(); } else if (n1) wait_vmcnt<4>();
+    if (n2) { dma(buf, 6, 8); WM_W2(12, 9); } else if (n1) WM_W2(4, 3);
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < QI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16<T>(b0[j][kh], a[i][kh], acc[4 + i][j]);
+        for (int j = 0; j < 2; ++j) acc[QI + i][j] = mfma16<T>(b0[j][kh], a[i][kh], acc[QI + i][j]);
     mfma_end();
   }
+#undef WM_W2
   if (wr == 0) __builtin_amdgcn_s_barrier();
-  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wr * WROWS, n0 + wc * 64, lane);
 }
 
-template <int T, int EPI, int DBG = 0>
+template <int T, int EPI, int DBG = 0, int QI = 4>
 hipError_t launch_pp2(const WmGemmArgs& a, hipStream_t s) {
-  constexpr size_t shm = 2 * 2 * 256 * 128;
-  const int ntn = (a.N + 255) / 256, ntm = (a.M + 255) / 256;
+  constexpr int BM = 64 * QI;
+  constexpr size_t shm = (size_t)2 * (BM + 256) * 128;
+  const int ntn = (a.N + 255) / 256, ntm = (a.M + BM - 1) / BM;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<T, EPI, 1, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<T, EPI, 1, DBG, QI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_pp2_kernel<T, EPI, 1, DBG>), dim3(ntm * ntn), dim3(512), shm, s, a);
+  hipLaunchKernelGGL((gemm_pp2_kernel<T, EPI, 1, DBG, QI>), dim3(ntm * ntn), dim3(512), shm, s, a);
   return hipGetLastError();
 }
 
@@ -857,7 +875,8 @@ hipError_t launch_pp(const WmGemmArgs& a, hipStream_t s) {
 
 template <int T, int EPI>
 hipError_t launch_pp_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
-  if (cfg == 4 && wm_tuning[WM_TUNE_GEMM_PP] != 3) return launch_pp2<T, EPI>(a, s);  // gemm_pp = 3 forces v1 on 256^2
+  if (cfg == 4 && wm_tuning[WM_TUNE_GEMM_PP] != 3) return launch_pp2<T, EPI>(a, s);  // gemm_pp = 3 forces v1
+  if (cfg == 5 && wm_tuning[WM_TUNE_GEMM_PP] != 3) return launch_pp2<T, EPI, 0, 3>(a, s);
   return cfg == 5 ? launch_pp<T, EPI, 3>(a, s) : launch_pp<T, EPI, 4>(a, s);
 }
 
