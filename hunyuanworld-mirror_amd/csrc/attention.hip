@@ -23,6 +23,14 @@
 
 namespace {
 
+// One 1-KiB LDS-DMA piece (16 B per lane) from inline asm: M0 carries the LDS destination; it is saved and restored
+// around the load so the compiler's own view of M0 stays valid (M0 is a reserved register: a clobber would not be honoured).
+__device__ __forceinline__ void wm_dma16(const void* g, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+
 constexpr int KVB = 64;                 // keys per tile
 constexpr int TILE_B = KVB * 64 * 2;    // 8 KiB per K or V tile
 constexpr float LOG2E = 1.4426950408889634f;
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
       vr = vr < seg_rows ? vr : seg_rows - 1;
       const u16* gk = kp + (size_t)kr * 64 + kd8 * 8;
       const u16* gv = vp + (size_t)vr * 64 + vd8 * 8;
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gk), "s"(dst + pc * 1024) : "m0", "memory");
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gv), "s"(dst + TILE_B + pc * 1024) : "m0", "memory");
+      wm_dma16(gk, dst + pc * 1024);
+      wm_dma16(gv, dst + TILE_B + pc * 1024);
     }
     if (++dma_j == ntpc) { dma_j = 0; ++dma_c; }
   };
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(256, MINW) void attn_sp_kernel(const WmAttnArgs p) 
         int row = nxt_j * KVB + key;
         row = row < seg_rows ? row : seg_rows - 1;  // clamped keys are masked (K) / multiplied by P = 0 (V)
         const u16* g = src + (size_t)row * 64 + d8 * 8;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst + i * 1024) : "m0", "memory");
+        wm_dma16(g, dst + i * 1024);
       }
     }
     if (tl >= -1) { if (++nxt_j == ntpc) { nxt_j = 0; ++nxt_c; } }
