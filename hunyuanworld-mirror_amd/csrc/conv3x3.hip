@@ -12,6 +12,8 @@
 #include "wm_common.h"
 #include "wm_kernels.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -302,6 +304,230 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Register-staged variant (plain input, 256- and 128-channel tiles).  In the kernel above a tap's MFMA work
+// (0.45-0.9 us) is shorter than one memory round trip and every tap drains vmcnt(0) — it has to, LDS-DMA and register
+// loads must not be mixed under counted waits — so the loop runs at the memory latency, not at the matrix pipe.
+// Here NOTHING uses LDS-DMA: weights and halo items are ordinary global loads into registers (returned in order, so
+// the compiler's own counted waits are safe), the weights of tap kt+2 are requested at the top of tap kt and written
+// to LDS at the end of tap kt+1 (two taps of flight), a halo item of the next chunk is requested at the top of a tap
+// and written at the end of the next one, and the tap barrier is a raw s_barrier behind an lgkmcnt(0) (a
+// __syncthreads() would drain the loads in flight).
+template <int T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
+  constexpr int BN = WN * TN * 32;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int WPT = BN * 8 / 512;  // 16-B weight chunks per thread per tap: 4 (256 ch) or 2 (128 ch)
+  static_assert(WM * WN == 8 && WM * TM * 32 == 256 && WPT >= 1, "8 waves x 256 pixels");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 halo][2 B]
+  char* hbuf = smem;
+  char* bbuf = smem + 2 * HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int H = p.Hi, W = p.Wi, Cin = p.Cin, Cout = p.Cout;
+  const int tiles_x = (W + TP - 1) / TP, tiles_y = (H + TP - 1) / TP, ctiles = (Cout + BN - 1) / BN;
+  const int nblk = p.N * tiles_y * tiles_x * ctiles;
+  int lid = xcd_remap(blockIdx.x, nblk);
+  const int ct = lid % ctiles; lid /= ctiles;
+  const int tx = lid % tiles_x; lid /= tiles_x;
+  const int ty = lid % tiles_y;
+  const int n = lid / tiles_y;
+  const int y0 = ty * TP, x0 = tx * TP, n0 = ct * BN;
+  const float* xin = p.x + (size_t)n * H * W * Cin;
+  const u16* Wt = (const u16*)p.w;
+  const int K = 9 * Cin;
+  const int nchunks = Cin / 64, NT = 9 * nchunks;
+
+  // ---- weights: thread -> WPT (cout row, 16-B chunk) pairs of the tile
+  const u16* wsrc[WPT];
+  int wdst[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int id = tid + i * 512, r = id >> 3, c = id & 7;
+    int co = n0 + r;
+    co = co < Cout ? co : Cout - 1;
+    wsrc[i] = Wt + (size_t)co * K + c * 8;
+    wdst[i] = r * 128 + ((c ^ swz(r)) << 4);
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vectors: HIP's uint4 / float4 structs kept these arrays in scratch
+  struct WSet { u32x4 v[WPT]; };
+  WSet wA, wB;  // two named register sets (an array of sets indexed by tap parity ends up in scratch memory)
+  auto w_load = [&](int kt, WSet& ws) {  // kt = 9 * chunk + tap
+    u32x4 (&w)[WPT] = ws.v;
+    const int cc = kt / 9, tap = kt - cc * 9;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) w[i] = *(const u32x4*)(wsrc[i] + tap * Cin + cc * 64);
+  };
+  auto w_store = [&](const WSet& ws, char* dst) {
+    const u32x4 (&w)[WPT] = ws.v;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) *(u32x4*)(dst + wdst[i]) = w[i];
+  };
+  // ---- halo items (plain input): two in flight
+  struct HItem { f32x4 v[2]; bool in; };
+  HItem hA, hB;
+  hA.in = hB.in = false;
+  auto h_load = [&](int cc, int i, HItem& it) {
+    const int id = tid + i * 512;
+    const int hr = id >> 3, ch = id & 7;
+    const int hy = hr / HW_, hx = hr - hy * HW_;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    it.in = id < HCH && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    if (it.in) {
+      const float* sp = xin + ((size_t)iy * W + ix) * Cin + cc * 64 + ch * 8;
+      it.v[0] = *(const f32x4*)sp;
+      it.v[1] = *(const f32x4*)(sp + 4);
+    }
+  };
+  auto h_store = [&](char* dst, int i, const HItem& it) {
+    const int id = tid + i * 512;
+    if (id >= HCH) return;
+    const int hr = id >> 3, ch = id & 7;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (it.in) {
+      v[0] = it.v[0][0]; v[1] = it.v[0][1]; v[2] = it.v[0][2]; v[3] = it.v[0][3];
+      v[4] = it.v[1][0]; v[5] = it.v[1][1]; v[6] = it.v[1][2]; v[7] = it.v[1][3];
+      if (p.relu_in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+    }
+    uint4 u;
+    u.x = (uint32_t)f2t<T>(v[0]) | ((uint32_t)f2t<T>(v[1]) << 16);
+    u.y = (uint32_t)f2t<T>(v[2]) | ((uint32_t)f2t<T>(v[3]) << 16);
+    u.z = (uint32_t)f2t<T>(v[4]) | ((uint32_t)f2t<T>(v[5]) << 16);
+    u.w = (uint32_t)f2t<T>(v[6]) | ((uint32_t)f2t<T>(v[7]) << 16);
+    *(uint4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = u;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int hbase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = (wm * TM + i) * 32 + (lane & 31);
+    hbase[i] = (r >> 4) * HW_ + (r & 15);
+  }
+
+  // ---- prologue: weights(0) and (1) requested, chunk 0's halo staged, weights(0) written
+  w_load(0, wA);
+  if (NT > 1) w_load(1, wB);
+  static_assert(HPT <= 7, "halo items: one per tap, written one tap later");
+#pragma unroll 1
+  for (int i = 0; i < HPT; i += 2) {
+    h_load(0, i, hA);
+    if (i + 1 < HPT) h_load(0, i + 1, hB);
+    h_store(hbuf, i, hA);
+    if (i + 1 < HPT) h_store(hbuf, i + 1, hB);
+  }
+  w_store(wA, bbuf);
+
+  // one tap; `mine` held weights(kt) (already in LDS) and receives weights(kt+2); `other` holds weights(kt+1).
+  // Two taps per loop iteration with the register sets swapped (a set array indexed by tap parity, or HIP's uint4 /
+  // float4 structs instead of native vectors, end up in scratch memory).  hipcc's waitcnt bookkeeping merges
+  // conservatively across the loop back-edge, so the ds_writes at the end of a tap still wait for the newest loads
+  // (fully unrolling 18 taps makes the waits exact but spills); even so this loop measures +8-22 % over the LDS-DMA
+  // one (tools/bench_conv.py): raw barrier, no vmcnt(0) drain at the top of the tap, no DMA issue.  Needs an even
+  // number of 64-channel chunks (the two-tap step walks chunk pairs).
+  auto tap_body = [&](int cc, int tap, int PAR, WSet& w_mine, WSet& w_other, HItem& h_mine, HItem& h_other) {
+    const int kt = cc * 9 + tap;
+    const char* hcur = hbuf + (cc & 1) * HALO_BYTES;
+    char* hnext = hbuf + ((cc + 1) & 1) * HALO_BYTES;
+    const bool more_chunks = cc + 1 < nchunks;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS writes of the previous tap are done
+    __builtin_amdgcn_s_barrier();                        // everybody finished tap kt-1; its LDS writes are visible
+    if (kt + 2 < NT) w_load(kt + 2, w_mine);
+    if (more_chunks && tap < HPT) h_load(cc + 1, tap, h_mine);
+    const char* tB = bbuf + PAR * B_BYTES;
+    const int toff = (tap / 3) * HW_ + (tap % 3);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ch = 2 * ks + (lane >> 5);
+      s16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int hr = hbase[i] + toff;
+        a[i] = *(const s16x8*)(hcur + hr * 128 + ((ch ^ swz(hr)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + (lane & 31);
+        b[j] = *(const s16x8*)(tB + row * 128 + ((ch ^ swz(row)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(b[j], a[i], acc[i][j]);
+    }
+    // end of tap: weights(kt+1) (requested at the top of tap kt-1) -> the buffer read during tap kt-1; the halo item
+    // requested at the top of tap kt-1 -> the next chunk's halo buffer (nobody reads it during this chunk)
+    if (kt + 1 < NT) w_store(w_other, bbuf + (PAR ^ 1) * B_BYTES);
+    if (more_chunks && tap >= 1 && tap <= HPT) h_store(hnext, tap - 1, h_other);
+  };
+  for (int cc0 = 0; cc0 < nchunks; cc0 += 2) {
+#pragma unroll 1
+    for (int u = 0; u < 18; u += 2) {
+      tap_body(cc0 + u / 9, u % 9, 0, wA, wB, hA, hB);
+      tap_body(cc0 + (u + 1) / 9, (u + 1) % 9, 1, wB, wA, hB, hA);
+    }
+  }
+
+  // ---- epilogue (same as conv3x3_kernel)
+  const int h4 = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = (wm * TM + i) * 32 + (lane & 31);
+    const int y = y0 + (r >> 4), x = x0 + (r & 15);
+    if (y >= H || x >= W) continue;
+    const size_t obase = (((size_t)n * H + y) * W + x) * Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cb = n0 + (wn * TN + j) * 32 + h4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = cb + 8 * g;
+        if (col >= Cout) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (p.bias) {
+          const float4 bs = *(const float4*)(p.bias + col);
+          v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+        }
+        if (p.resid) {
+          float4 rr = *(const float4*)(p.resid + obase + col);
+          if (p.resid_relu) rr = make_float4(fmaxf(rr.x, 0.f), fmaxf(rr.y, 0.f), fmaxf(rr.z, 0.f), fmaxf(rr.w, 0.f));
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.resid2) {
+          const float4 rr = *(const float4*)(p.resid2 + obase + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        *(float4*)(p.y + obase + col) = v;
+      }
+    }
+  }
+}
+
+template <int T, int WM, int WN, int TM, int TN>
+hipError_t launch_rs(const WmConvArgs& a, hipStream_t s) {
+  constexpr int BN = WN * TN * 32;
+  const size_t shm = 2 * HALO_BYTES + 2 * BN * 128;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_rs_kernel<T, WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr = true;
+  }
+  const int nblk = a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP) * ((a.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL((conv3x3_rs_kernel<T, WM, WN, TM, TN>), dim3(nblk), dim3(512), shm, s, a);
+  return hipGetLastError();
+}
+
 template <int T, int WM, int WN, int TM, int TN, int NARROW = 0>
 hipError_t launch_cfg(const WmConvArgs& a, hipStream_t s) {
   constexpr int BN = WN * TN * 32;
@@ -327,9 +553,10 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   int bn = a.Cout > 128 ? 256 : a.Cout > 64 ? 128 : a.Cout > 32 ? 64 : 32;
   while (bn > 64 && 2 * ptiles * ((a.Cout + bn - 1) / bn) < ncu) bn >>= 1;
   if (wm_tuning[WM_TUNE_CONV_BN] > 0) bn = wm_tuning[WM_TUNE_CONV_BN];
-  if (bn >= 256) return launch_cfg<T, 2, 4, 4, 2>(a, s);   // 256 px x 256 ch (a two-group ping-pong main loop was tried here: bit-identical, no faster)
-  if (bn >= 128) return launch_cfg<T, 4, 2, 2, 2>(a, s);   // 256 px x 128 ch
-  if (bn >= 64) return launch_cfg<T, 4, 2, 2, 1>(a, s);    // 256 px x 64 ch
+  const bool rs = a.up_hs == 0 && (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0;  // register-staged main loop (plain input, even chunk count)
+  if (bn >= 256) return rs ? launch_rs<T, 2, 4, 4, 2>(a, s) : launch_cfg<T, 2, 4, 4, 2>(a, s);   // 256 px x 256 ch (a two-group ping-pong main loop was tried here: bit-identical, no faster)
+  if (bn >= 128) return rs ? launch_rs<T, 4, 2, 2, 2>(a, s) : launch_cfg<T, 4, 2, 2, 2>(a, s);   // 256 px x 128 ch
+  if (bn >= 64) return launch_cfg<T, 4, 2, 2, 1>(a, s);    // 256 px x 64 ch (register staging measured equal here)
   if (wm_tuning[WM_TUNE_CONV_NARROW] == 0) return launch_cfg<T, 8, 1, 1, 1>(a, s);  // per-tap loop (A/B)
   return launch_cfg<T, 8, 1, 1, 1, 1>(a, s);               // 256 px x 32 ch, narrow variant
 }

@@ -1,4 +1,4 @@
-"""GPU micro-benchmark of the 3x3 conv on the DPT shapes; A/B of the ping-pong main loop (conv_pp) in one process."""
+"""GPU micro-benchmark of the 3x3 conv on the DPT shapes; in-process A/B of the register-staged main loop (conv_rs)."""
 import ctypes as C, sys, json, math
 import torch
 sys.path.insert(0, '.')
@@ -13,8 +13,8 @@ for (N, H, W, Cin, Cout) in [(8, 148, 148, 256, 256), (8, 74, 74, 256, 256), (8,
     fl = 2.0 * N * H * W * Cout * 9 * Cin
     res = {}; outs = {}
     for rep in range(2):
-        for label, pp in (("bn256", 256), ("bn128", 128), ("bn64", 64), ("auto", -1)):
-            tune("conv_bn", pp)
+        for label, pp in (("dma_lockstep", 0), ("reg_staged", 1)):
+            tune("conv_rs", pp)
             for _ in range(2): L.wm_op_conv(1, p(x), p(w16), p(b), p(r1), None, p(y), N, H, W, Cin, Cout, 3, 1, 1, 1, 1, s)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -22,5 +22,5 @@ for (N, H, W, Cin, Cout) in [(8, 148, 148, 256, 256), (8, 74, 74, 256, 256), (8,
             e1.record(); torch.cuda.synchronize()
             res.setdefault(label, []).append(round(fl / (e0.elapsed_time(e1) / 10) / 1e9))
             outs[label] = y.clone()
-    d = float((outs["bn256"] - outs["bn64"]).abs().max())
+    d = float((outs["dma_lockstep"] - outs["reg_staged"]).abs().max())
     print(json.dumps({"shape": [N, H, W, Cin, Cout], "tflops": res, "max_abs_diff": d}), flush=True)
