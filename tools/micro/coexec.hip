@@ -63,3 +63,4 @@ int main() {
   }
   return 0;
 }
+// build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -o tools/micro/coexec tools/micro/coexec.hip && tools/micro/coexec
