@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const WmConvArgs p) {
   const int cin_tiles = p.Cin / BK;
   const int nk = p.ksize * p.ksize * cin_tiles;
 
-  float4 areg[APT][2];
+  f32x4 areg[APT][2];  // native vectors: each is tied to the explicit wait in store_a
   auto load_a = [&](int kt) {
     const int tap = kt / cin_tiles, ci0 = (kt - tap * cin_tiles) * BK;
     const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
@@ -89,11 +89,11 @@ __global__ __launch_bounds__(256) void conv_kernel(const WmConvArgs p) {
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
       if (a_ok[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) {
         const float* s = a_base[i] + ((size_t)iy * p.Wi + ix) * p.Cin + ci0;
-        areg[i][0] = *(const float4*)s;
-        areg[i][1] = *(const float4*)(s + 4);
+        areg[i][0] = *(const f32x4*)s;
+        areg[i][1] = *(const f32x4*)(s + 4);
       } else {
-        areg[i][0] = make_float4(0, 0, 0, 0);
-        areg[i][1] = make_float4(0, 0, 0, 0);
+        areg[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        areg[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -101,8 +101,11 @@ __global__ __launch_bounds__(256) void conv_kernel(const WmConvArgs p) {
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       const int id = tid + i * 256, r = id / CPR, c = id % CPR;
-      float v[8] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w,
-                    areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
+      // released by a full drain the registers are tied to (hipcc's own waits consumed these loop-carried loads
+      // too early with LDS-DMA in flight; untied register math may be hoisted above a bare asm wait)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(areg[i][0]), "+v"(areg[i][1]) : : "memory");
+      float v[8] = {areg[i][0][0], areg[i][0][1], areg[i][0][2], areg[i][0][3],
+                    areg[i][1][0], areg[i][1][1], areg[i][1][2], areg[i][1][3]};
       if (p.relu_in) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);

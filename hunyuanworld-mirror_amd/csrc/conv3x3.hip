@@ -63,15 +63,15 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
   const float usx = up && W > 1 ? (float)(p.up_ws - 1) / (float)(W - 1) : 0.f;
   if (up) xin = p.x + (size_t)n * p.up_hs * p.up_ws * Cin;
   struct HaloItem {
-    float4 hv[4][2];     // plain: hv[0]; up: the 4 corners
-    float4 ha[2];        // position-table add (up mode with tables)
+    f32x4 hv[4][2];      // plain: hv[0]; up: the 4 corners (native vectors: they are tied to the wait below)
+    f32x4 ha[2];         // position-table add (up mode with tables)
     float hw[4];         // corner weights
     bool in;             // the halo pixel lies inside the image
   };
   HaloItem it0;
   it0.in = false;
   auto halo_load_it = [&](HaloItem& it, int cc, int i) {
-    float4 (&hv)[4][2] = it.hv; float4 (&ha)[2] = it.ha; float (&hw)[4] = it.hw; bool& h_in = it.in;
+    f32x4 (&hv)[4][2] = it.hv; f32x4 (&ha)[2] = it.ha; float (&hw)[4] = it.hw; bool& h_in = it.in;
     const int id = tid + i * 512;
     const int hr = id >> 3, ch = id & 7;
     const int hy = hr / HW_, hx = hr - hy * HW_;
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
     const int c0 = cc * 64 + ch * 8;
     if (!up) {
       const float* s = xin + ((size_t)iy * W + ix) * Cin + c0;
-      hv[0][0] = *(const float4*)s;
-      hv[0][1] = *(const float4*)(s + 4);
+      hv[0][0] = *(const f32x4*)s;
+      hv[0][1] = *(const f32x4*)(s + 4);
     } else {
       const float fy = usy * iy, fx = usx * ix;
       int ya = (int)fy, xa = (int)fx;
@@ -95,38 +95,45 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
       const float* s01 = xin + ((size_t)ya * p.up_ws + xb) * Cin + c0;
       const float* s10 = xin + ((size_t)yb * p.up_ws + xa) * Cin + c0;
       const float* s11 = xin + ((size_t)yb * p.up_ws + xb) * Cin + c0;
-      hv[0][0] = *(const float4*)s00; hv[0][1] = *(const float4*)(s00 + 4);
-      hv[1][0] = *(const float4*)s01; hv[1][1] = *(const float4*)(s01 + 4);
-      hv[2][0] = *(const float4*)s10; hv[2][1] = *(const float4*)(s10 + 4);
-      hv[3][0] = *(const float4*)s11; hv[3][1] = *(const float4*)(s11 + 4);
+      hv[0][0] = *(const f32x4*)s00; hv[0][1] = *(const f32x4*)(s00 + 4);
+      hv[1][0] = *(const f32x4*)s01; hv[1][1] = *(const f32x4*)(s01 + 4);
+      hv[2][0] = *(const f32x4*)s10; hv[2][1] = *(const f32x4*)(s10 + 4);
+      hv[3][0] = *(const f32x4*)s11; hv[3][1] = *(const f32x4*)(s11 + 4);
       if (p.up_addx) {
         const int half = Cin >> 1;
         const float* t = c0 < half ? p.up_addx + (size_t)ix * half + c0 : p.up_addy + (size_t)iy * half + (c0 - half);
-        ha[0] = *(const float4*)t; ha[1] = *(const float4*)(t + 4);
+        ha[0] = *(const f32x4*)t; ha[1] = *(const f32x4*)(t + 4);
       }
     }
   };
   auto halo_store_it = [&](HaloItem& it, char* dst, int i) {
-    float4 (&hv)[4][2] = it.hv; float4 (&ha)[2] = it.ha; float (&hw)[4] = it.hw; const bool h_in = it.in;
+    // The item's registers are released by an explicit full drain that they are tied to: hipcc's own waitcnt
+    // insertion consumed loop-carried loads too early in these kernels (LDS-DMA in flight), and untied register-only
+    // math may be hoisted above a bare asm wait.  Every call site sits right behind a vmcnt(0) anyway.
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(it.hv[0][0]), "+v"(it.hv[0][1]), "+v"(it.hv[1][0]), "+v"(it.hv[1][1]), "+v"(it.hv[2][0]),
+                 "+v"(it.hv[2][1]), "+v"(it.hv[3][0]), "+v"(it.hv[3][1]), "+v"(it.ha[0]), "+v"(it.ha[1]) : : "memory");
+    f32x4 (&hv)[4][2] = it.hv; f32x4 (&ha)[2] = it.ha; float (&hw)[4] = it.hw; const bool h_in = it.in;
     const int id = tid + i * 512;
     if (id >= HCH) return;
     const int hr = id >> 3, ch = id & 7;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (h_in) {
       if (!up) {
-        v[0] = hv[0][0].x; v[1] = hv[0][0].y; v[2] = hv[0][0].z; v[3] = hv[0][0].w;
-        v[4] = hv[0][1].x; v[5] = hv[0][1].y; v[6] = hv[0][1].z; v[7] = hv[0][1].w;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = hv[0][q][e];
       } else {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          v[4 * q + 0] = hw[0] * hv[0][q].x + hw[1] * hv[1][q].x + hw[2] * hv[2][q].x + hw[3] * hv[3][q].x;
-          v[4 * q + 1] = hw[0] * hv[0][q].y + hw[1] * hv[1][q].y + hw[2] * hv[2][q].y + hw[3] * hv[3][q].y;
-          v[4 * q + 2] = hw[0] * hv[0][q].z + hw[1] * hv[1][q].z + hw[2] * hv[2][q].z + hw[3] * hv[3][q].z;
-          v[4 * q + 3] = hw[0] * hv[0][q].w + hw[1] * hv[1][q].w + hw[2] * hv[2][q].w + hw[3] * hv[3][q].w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = hw[0] * hv[0][q][e] + hw[1] * hv[1][q][e] + hw[2] * hv[2][q][e] + hw[3] * hv[3][q][e];
         }
         if (p.up_addx) {
-          v[0] += ha[0].x; v[1] += ha[0].y; v[2] += ha[0].z; v[3] += ha[0].w;
-          v[4] += ha[1].x; v[5] += ha[1].y; v[6] += ha[1].z; v[7] += ha[1].w;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] += ha[q][e];
         }
       }
       if (p.relu_in) {
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
 // to LDS at the end of tap kt+1 (two taps of flight), a halo item of the next chunk is requested at the top of a tap
 // and written at the end of the next one, and the tap barrier is a raw s_barrier behind an lgkmcnt(0) (a
 // __syncthreads() would drain the loads in flight).
-template <int T, int WM, int WN, int TM, int TN>
+template <int T, int WM, int WN, int TM, int TN, int UP = 0>
 __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
   constexpr int BN = WN * TN * 32;
   constexpr int B_BYTES = BN * 128;
@@ -334,7 +341,9 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
   const int ty = lid % tiles_y;
   const int n = lid / tiles_y;
   const int y0 = ty * TP, x0 = tx * TP, n0 = ct * BN;
-  const float* xin = p.x + (size_t)n * H * W * Cin;
+  const float* xin = UP ? p.x + (size_t)n * p.up_hs * p.up_ws * Cin : p.x + (size_t)n * H * W * Cin;
+  const float usy = UP && H > 1 ? (float)(p.up_hs - 1) / (float)(H - 1) : 0.f;
+  const float usx = UP && W > 1 ? (float)(p.up_ws - 1) / (float)(W - 1) : 0.f;
   const u16* Wt = (const u16*)p.w;
   const int K = 9 * Cin;
   const int nchunks = Cin / 64, NT = 9 * nchunks;
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     for (int i = 0; i < WPT; ++i) *(u32x4*)(dst + wdst[i]) = w[i];
   };
   // ---- halo items (plain input): two in flight
-  struct HItem { f32x4 v[2]; bool in; };
+  struct HItem { f32x4 v[UP ? 4 : 1][2]; f32x4 t[2]; float w[4]; bool in; };  // UP: 4 corners, position-table add, weights
   HItem hA, hB;
   hA.in = hB.in = false;
   auto h_load = [&](int cc, int i, HItem& it) {
@@ -374,10 +383,34 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     const int hy = hr / HW_, hx = hr - hy * HW_;
     const int iy = y0 + hy - 1, ix = x0 + hx - 1;
     it.in = id < HCH && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int c0 = cc * 64 + ch * 8;
     if (it.in) {
-      const float* sp = xin + ((size_t)iy * W + ix) * Cin + cc * 64 + ch * 8;
-      it.v[0] = *(const f32x4*)sp;
-      it.v[1] = *(const f32x4*)(sp + 4);
+      if constexpr (!UP) {
+        const float* sp = xin + ((size_t)iy * W + ix) * Cin + c0;
+        it.v[0][0] = *(const f32x4*)sp;
+        it.v[0][1] = *(const f32x4*)(sp + 4);
+      } else {
+        const float fy = usy * iy, fx = usx * ix;
+        int ya = (int)fy, xa = (int)fx;
+        ya = ya < p.up_hs - 1 ? ya : p.up_hs - 1;
+        xa = xa < p.up_ws - 1 ? xa : p.up_ws - 1;
+        const int yb = ya < p.up_hs - 1 ? ya + 1 : ya, xb = xa < p.up_ws - 1 ? xa + 1 : xa;
+        const float wy = fy - ya, wx = fx - xa;
+        it.w[0] = (1.f - wy) * (1.f - wx); it.w[1] = (1.f - wy) * wx; it.w[2] = wy * (1.f - wx); it.w[3] = wy * wx;
+        const float* s00 = xin + ((size_t)ya * p.up_ws + xa) * Cin + c0;
+        const float* s01 = xin + ((size_t)ya * p.up_ws + xb) * Cin + c0;
+        const float* s10 = xin + ((size_t)yb * p.up_ws + xa) * Cin + c0;
+        const float* s11 = xin + ((size_t)yb * p.up_ws + xb) * Cin + c0;
+        it.v[0][0] = *(const f32x4*)s00; it.v[0][1] = *(const f32x4*)(s00 + 4);
+        it.v[1][0] = *(const f32x4*)s01; it.v[1][1] = *(const f32x4*)(s01 + 4);
+        it.v[2][0] = *(const f32x4*)s10; it.v[2][1] = *(const f32x4*)(s10 + 4);
+        it.v[3][0] = *(const f32x4*)s11; it.v[3][1] = *(const f32x4*)(s11 + 4);
+        if (p.up_addx) {
+          const int half = Cin >> 1;
+          const float* t = c0 < half ? p.up_addx + (size_t)ix * half + c0 : p.up_addy + (size_t)iy * half + (c0 - half);
+          it.t[0] = *(const f32x4*)t; it.t[1] = *(const f32x4*)(t + 4);
+        }
+      }
     }
   };
   auto h_store = [&](char* dst, int i, const HItem& it) {
@@ -386,8 +419,24 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     const int hr = id >> 3, ch = id & 7;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (it.in) {
-      v[0] = it.v[0][0]; v[1] = it.v[0][1]; v[2] = it.v[0][2]; v[3] = it.v[0][3];
-      v[4] = it.v[1][0]; v[5] = it.v[1][1]; v[6] = it.v[1][2]; v[7] = it.v[1][3];
+      if constexpr (!UP) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = it.v[0][q][e];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[4 * q + e] = it.w[0] * it.v[0][q][e] + it.w[1] * it.v[1][q][e] + it.w[2] * it.v[2][q][e] + it.w[3] * it.v[3][q][e];
+        if (p.up_addx) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] += it.t[q][e];
+        }
+      }
       if (p.relu_in) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -400,6 +449,43 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     u.w = (uint32_t)f2t<T>(v[6]) | ((uint32_t)f2t<T>(v[7]) << 16);
     *(uint4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = u;
   };
+
+  // Explicit counted waits, tied to the registers they release.  hipcc's own waitcnt insertion is NOT relied upon
+  // for these loop-carried loads: with the loads issued a tap (or two) before their use, under conditions, it
+  // consumed stale registers (sparse wrong halo pixels, run-to-run different), while the hardware itself completes
+  // loads in issue order (tools/micro/vmorder.hip) — so "at most n younger loads outstanding" is exact.
+#define WM_VMW(kk) case kk: asm volatile("s_waitcnt vmcnt(" #kk ")" : WM_TIE : : "memory"); break;
+#define WM_VMW_ALL WM_VMW(0) WM_VMW(2) WM_VMW(4) WM_VMW(6) WM_VMW(8) WM_VMW(10) WM_VMW(12) WM_VMW(14) WM_VMW(16) WM_VMW(18) WM_VMW(20) WM_VMW(22) WM_VMW(24)
+  auto wait_w = [&](int n, WSet& ws) {  // ws is complete once at most n younger loads are outstanding
+    if constexpr (WPT == 4) {
+#define WM_TIE "+v"(ws.v[0]), "+v"(ws.v[1]), "+v"(ws.v[2]), "+v"(ws.v[3])
+      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
+#undef WM_TIE
+    } else if constexpr (WPT == 2) {
+#define WM_TIE "+v"(ws.v[0]), "+v"(ws.v[1])
+      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
+#undef WM_TIE
+    } else {
+#define WM_TIE "+v"(ws.v[0])
+      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
+#undef WM_TIE
+    }
+  };
+  auto wait_h = [&](int n, HItem& it) {
+    if constexpr (UP) {
+#define WM_TIE "+v"(it.v[0][0]), "+v"(it.v[0][1]), "+v"(it.v[1][0]), "+v"(it.v[1][1]), "+v"(it.v[2][0]), "+v"(it.v[2][1]), \
+               "+v"(it.v[UP ? 3 : 0][0]), "+v"(it.v[UP ? 3 : 0][1]), "+v"(it.t[0]), "+v"(it.t[1])
+      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
+#undef WM_TIE
+    } else {
+#define WM_TIE "+v"(it.v[0][0]), "+v"(it.v[0][1])
+      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
+#undef WM_TIE
+    }
+  };
+#undef WM_VMW_ALL
+#undef WM_VMW
+  const int LI = UP ? (p.up_addx ? 10 : 8) : 2;  // loads per halo item
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -423,9 +509,13 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
   for (int i = 0; i < HPT; i += 2) {
     h_load(0, i, hA);
     if (i + 1 < HPT) h_load(0, i + 1, hB);
+    wait_h(0, hA);
+    if (i + 1 < HPT) wait_h(0, hB);
     h_store(hbuf, i, hA);
     if (i + 1 < HPT) h_store(hbuf, i + 1, hB);
   }
+  wait_w(0, wA);
+  wait_w(0, wB);
   w_store(wA, bbuf);
 
   // one tap; `mine` held weights(kt) (already in LDS) and receives weights(kt+2); `other` holds weights(kt+1).
@@ -467,8 +557,17 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     }
     // end of tap: weights(kt+1) (requested at the top of tap kt-1) -> the buffer read during tap kt-1; the halo item
     // requested at the top of tap kt-1 -> the next chunk's halo buffer (nobody reads it during this chunk)
-    if (kt + 1 < NT) w_store(w_other, bbuf + (PAR ^ 1) * B_BYTES);
-    if (more_chunks && tap >= 1 && tap <= HPT) h_store(hnext, tap - 1, h_other);
+    // in flight, youngest last: W(kt+1) | item(tap-1) | W(kt+2) | item(tap)  (each only if it was requested)
+    const int young = (kt + 2 < NT ? WPT : 0) + (more_chunks && tap < HPT ? LI : 0);  // requested at the top of THIS tap
+    const bool st_h = more_chunks && tap >= 1 && tap <= HPT;
+    if (kt + 1 < NT) {
+      wait_w(young + (st_h ? LI : 0), w_other);
+      w_store(w_other, bbuf + (PAR ^ 1) * B_BYTES);
+    }
+    if (st_h) {
+      wait_h(young, h_other);
+      h_store(hnext, tap - 1, h_other);
+    }
   };
   for (int cc0 = 0; cc0 < nchunks; cc0 += 2) {
 #pragma unroll 1
@@ -514,17 +613,17 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
   }
 }
 
-template <int T, int WM, int WN, int TM, int TN>
+template <int T, int WM, int WN, int TM, int TN, int UP = 0>
 hipError_t launch_rs(const WmConvArgs& a, hipStream_t s) {
   constexpr int BN = WN * TN * 32;
   const size_t shm = 2 * HALO_BYTES + 2 * BN * 128;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_rs_kernel<T, WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)conv3x3_rs_kernel<T, WM, WN, TM, TN, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
   const int nblk = a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP) * ((a.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL((conv3x3_rs_kernel<T, WM, WN, TM, TN>), dim3(nblk), dim3(512), shm, s, a);
+  hipLaunchKernelGGL((conv3x3_rs_kernel<T, WM, WN, TM, TN, UP>), dim3(nblk), dim3(512), shm, s, a);
   return hipGetLastError();
 }
 
@@ -553,7 +652,9 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   int bn = a.Cout > 128 ? 256 : a.Cout > 64 ? 128 : a.Cout > 32 ? 64 : 32;
   while (bn > 64 && 2 * ptiles * ((a.Cout + bn - 1) / bn) < ncu) bn >>= 1;
   if (wm_tuning[WM_TUNE_CONV_BN] > 0) bn = wm_tuning[WM_TUNE_CONV_BN];
-  const bool rs = a.up_hs == 0 && (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0;  // register-staged main loop (plain input, even chunk count)
+  const bool rs_ok = (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0;
+  const bool rs = rs_ok && a.up_hs == 0;  // register-staged main loop (plain input, even chunk count)
+  if (rs_ok && a.up_hs > 0 && bn == 128) return launch_rs<T, 4, 2, 2, 2, 1>(a, s);  // fused resize, 128-channel tile
   if (bn >= 256) return rs ? launch_rs<T, 2, 4, 4, 2>(a, s) : launch_cfg<T, 2, 4, 4, 2>(a, s);   // 256 px x 256 ch (a two-group ping-pong main loop was tried here: bit-identical, no faster)
   if (bn >= 128) return rs ? launch_rs<T, 4, 2, 2, 2>(a, s) : launch_cfg<T, 4, 2, 2, 2>(a, s);   // 256 px x 128 ch
   if (bn >= 64) return launch_cfg<T, 4, 2, 2, 1>(a, s);    // 256 px x 64 ch (register staging measured equal here)
