@@ -65,7 +65,6 @@ template <int T, int NW, int QB, int MINW, int LZ = 1, int STG = 1>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int QT = NW * 32 * QB;  // query rows per block; each wave owns QB blocks of 32 rows
-  constexpr int CPT = 512 / NT;     // 16-B chunks per thread per tile (K and V each)
   constexpr int NBUF = STG == 2 ? 3 : 2;  // STG 2: three-deep ring, tiles fetched two ahead
   __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_B];  // [buf][K|V]
 
@@ -108,9 +107,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   const u16* Kb = (const u16*)p.K + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
 
-  // STG 1: tiles stream by LDS-DMA (1-KiB pieces; the source-side permutation builds the swizzled K rows and the
-  // blocked V image; issued from inline asm — hipcc would order every later ds_read behind a DMA it can see with a
-  // vmcnt(0)); the wait is the explicit one before the barrier.  STG 0: global -> registers -> ds_write.
+  // Tiles stream by LDS-DMA (1-KiB pieces; the source-side permutation builds the swizzled K rows and the blocked V
+  // image; issued from inline asm — hipcc would order every later ds_read behind a DMA it can see with a vmcnt(0));
+  // the wait is the explicit one before the barrier.  STG 2: three-deep ring, two tiles ahead (measured equal).
   typedef __attribute__((address_space(3))) void* lds_vp0;
   int dma_c = 0, dma_j = 0;  // (chunk, tile in chunk) of the next tile to fetch: tiles are fetched in order from t0
   auto dma_tile = [&](int buf) {
@@ -134,35 +133,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
     }
     if (++dma_j == ntpc) { dma_j = 0; ++dma_c; }
   };
-  uint4 kreg[CPT], vreg[CPT];
-  auto load_tile = [&](int t) {
-    const int c = t / ntpc, j = t - c * ntpc;
-    const u16* kp = Kb + (size_t)c * p.kv_chunk_stride;
-    const u16* vp = Vb + (size_t)c * p.kv_chunk_stride;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int ch = tid + i * NT, key = ch >> 3, d8 = ch & 7;
-      const int krow = j * KVB + key;
-      if (krow < seg_rows) {
-        kreg[i] = *(const uint4*)(kp + (size_t)krow * 64 + d8 * 8);
-        vreg[i] = *(const uint4*)(vp + (size_t)krow * 64 + d8 * 8);
-      } else {
-        kreg[i] = make_uint4(0, 0, 0, 0);
-        vreg[i] = make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* kt = smem + buf * 2 * TILE_B;
-    char* vt = kt + TILE_B;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int ch = tid + i * NT, key = ch >> 3, d8 = ch & 7;
-      *(uint4*)(kt + key * 128 + ((d8 ^ ((key >> 1) & 7)) << 4)) = kreg[i];
-      *(uint4*)(vt + (((key >> 2) * 2 + (d8 >> 2)) << 8) + ((key & 3) << 6) + ((d8 & 3) << 4)) = vreg[i];
-    }
-  };
-
   // Scores arrive in log2 units (q is pre-scaled by log2(e)/sqrt(d)).  The running max is subtracted
   // INSIDE the MFMA: one extra k-step multiplies a constant K-side fragment (1.0 at k=0) with a Q-side
   // fragment holding -m_run at k=0, so S' = S - m_run comes out of the matrix pipe and the softmax
@@ -189,15 +159,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   // this block's slice of the key tiles (every slice is non-empty: the launcher keeps kv_splits <= ntiles)
   const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
   constexpr int DPW = 2 * (8 / NW);  // DMA instructions per wave per tile
-  if (STG) {
-    dma_c = t0 / ntpc; dma_j = t0 - dma_c * ntpc;
-    dma_tile(0);
-    if (STG == 2 && t0 + 1 < t1) { dma_tile(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    load_tile(t0);
-    store_tile(0);
-  }
+  dma_c = t0 / ntpc; dma_j = t0 - dma_c * ntpc;
+  dma_tile(0);
+  if (STG == 2 && t0 + 1 < t1) { dma_tile(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // per-lane constant part of the transposed V read address (see header)
@@ -210,8 +175,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
     if (STG == 2) {
       if (t + 2 < t1) dma_tile((t - t0 + 2) % 3);  // the buffer of tile t-1: everybody passed the barrier that ended it
     } else if (t + 1 < t1) {
-      if (STG) dma_tile(cur ^ 1);  // everybody passed the barrier that ended tile t-1: the other buffer is free
-      else load_tile(t + 1);       // global -> regs, hidden under the MFMA phase
+      dma_tile(cur ^ 1);  // everybody passed the barrier that ended tile t-1: the other buffer is free
     }
 
     // ---- S^T = K Q^T : st[b][k2][r] = S[key = 32k2 + (r&3)+8(r>>2)+4h][q = ql of block b]
@@ -333,8 +297,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
     if (STG == 2) {  // tile t+1 must have landed; tile t+2 (if any) may stay in flight
       if (t + 2 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (t + 1 < t1) store_tile(cur ^ 1);
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -742,7 +705,6 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0>(a, s);  // eager max (A/B)
   if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0>(a, s);
   if (qb == 13) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 1, 2>(a, s) : launch<WM_T_F16, 4, 2, 2, 1, 2>(a, s);  // 3-deep DMA ring
-  if (qb == 12) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 1, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 1, 0>(a, s);  // register staging (A/B)
   if (qb == 2) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 1>(a, s) : launch<WM_T_F16, 4, 2, 1>(a, s);
   if (qb == 3) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s) : launch<WM_T_F16, 4, 2, 2>(a, s);
   if (qb == 4) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3>(a, s) : launch<WM_T_F16, 4, 1, 3>(a, s);
