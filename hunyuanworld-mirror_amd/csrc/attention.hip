@@ -678,9 +678,11 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
     int best = 1;
     if (a.kv_splits > 0) best = a.kv_splits < lim ? a.kv_splits : lim;
     else if (wm_tuning[WM_TUNE_ATTN_SPLITS] > 0) best = wm_tuning[WM_TUNE_ATTN_SPLITS] < lim ? wm_tuning[WM_TUNE_ATTN_SPLITS] : lim;
-    // no automatic split: measured (tools/bench_attn.py) 8-view cross-view attention is the same speed at 1-4 splits and
-    // the short per-frame sequences lose 15-20 % — a wave that is alone on its SIMD runs its tiles about twice as fast,
-    // so a partly filled last round costs nothing.  (blocks, slots kept for the tuning hook / future kernels.)
+    // Automatic split only on the view-sharded path (kv_chunks > 1: 8 local views of queries against all ranks' keys):
+    // the q-tiles alone give 1.3 rounds of long blocks there and 4 slices measure +18 % at 8 chunks, +7 % at 4, +6 % at
+    // 2 (tools/bench_attn_split_chunks.py).  On one GPU (kv_chunks == 1) the combine pass costs what the better
+    // balance gains (8 views: 940 vs 940 TF/s) and the short per-frame sequences lose 20 %.
+    else if (a.kv_chunks > 1 && lim >= 2) best = lim < 4 ? lim : 4;
     (void)blocks; (void)slots;
     a.kv_splits = best;
   }

@@ -54,6 +54,47 @@ def test_two_virtual_ranks_match_single(name):
     L.wm_local_group_destroy(grp)
 
 
+def test_two_virtual_ranks_long_sequences_use_split_kv():
+    """6 views of 392 x 392 on the scaled-down architecture: 791 tokens per view, so on the sharded path cross-view
+    attention sees 2 chunks x 38 key tiles and the launcher's automatic 4-way split-KV (+ combine pass) engages.
+    No golden at this size: the sharded result must equal the single-rank result (bf16 noise floor)."""
+    from hunyuanworld_mirror_amd import WorldMirror, WMConfig, _lib
+    cfg = WMConfig.tiny()
+    g = torch.Generator().manual_seed(7)
+    tv = {"img": torch.rand(1, 6, 3, 392, 392, generator=g).cuda()}
+    single = WorldMirror(arch=cfg).init_synthetic_weights().to("cuda:0")
+    ref = single(tv)
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    world = 2
+    grp = C.c_void_p(L.wm_local_group_create(world))
+    models = [WorldMirror(arch=cfg).init_synthetic_weights().to("cuda:0").shard_local(grp, r, world) for r in range(world)]
+    res, errs = [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            res[r] = models[r](tv)
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(180)
+    assert not errs, errs
+    assert all(not t.is_alive() for t in th), "sharded forward deadlocked"
+    for k in ("pts3d", "depth", "normals"):
+        got = torch.cat([res[r][k] for r in range(world)], 1)
+        assert torch.isfinite(got).all(), k
+        e = rel_l2(got.cpu().numpy(), ref[k].cpu().numpy())
+        print("392^2 x 6 views", k, f"sharded (split-KV) vs single: {e:.2e}")
+        assert e < 3e-3, k
+    del models
+    L.wm_local_group_destroy(grp)
+
+
 def test_rccl_allgather_path_single_rank():
     """The RCCL collective itself (ncclAllGather on the handle's own communicator) at world size 1:
     WM_FORCE_GATHER routes global attention through the gathered-K/V path.  Run in a subprocess because
