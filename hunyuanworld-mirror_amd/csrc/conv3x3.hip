@@ -450,41 +450,22 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     *(uint4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = u;
   };
 
-  // Explicit counted waits, tied to the registers they release.  hipcc's own waitcnt insertion is NOT relied upon
-  // for these loop-carried loads: with the loads issued a tap (or two) before their use, under conditions, it
-  // consumed stale registers (sparse wrong halo pixels, run-to-run different), while the hardware itself completes
-  // loads in issue order (tools/micro/vmorder.hip) — so "at most n younger loads outstanding" is exact.
-#define WM_VMW(kk) case kk: asm volatile("s_waitcnt vmcnt(" #kk ")" : WM_TIE : : "memory"); break;
-#define WM_VMW_ALL WM_VMW(0) WM_VMW(2) WM_VMW(4) WM_VMW(6) WM_VMW(8) WM_VMW(10) WM_VMW(12) WM_VMW(14) WM_VMW(16) WM_VMW(18) WM_VMW(20) WM_VMW(22) WM_VMW(24)
-  auto wait_w = [&](int n, WSet& ws) {  // ws is complete once at most n younger loads are outstanding
-    if constexpr (WPT == 4) {
-#define WM_TIE "+v"(ws.v[0]), "+v"(ws.v[1]), "+v"(ws.v[2]), "+v"(ws.v[3])
-      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
-#undef WM_TIE
-    } else if constexpr (WPT == 2) {
-#define WM_TIE "+v"(ws.v[0]), "+v"(ws.v[1])
-      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
-#undef WM_TIE
-    } else {
-#define WM_TIE "+v"(ws.v[0])
-      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
-#undef WM_TIE
-    }
+  // Explicit waits, tied to the registers they release.  hipcc's own waitcnt insertion is NOT relied upon for these
+  // loop-carried loads: with the loads issued a tap (or two) before their use, under conditions, it consumed stale
+  // registers (sparse wrong halo pixels, run-to-run different), while the hardware itself completes loads in issue
+  // order (tools/micro/vmorder.hip).
+  auto wait_w = [&](int, WSet& ws) {  // full drain (hipcc's own merged waits drained here too; a switch over exact counts cost more than it saved)
+    if constexpr (WPT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ws.v[0]), "+v"(ws.v[1]), "+v"(ws.v[2]), "+v"(ws.v[3]) : : "memory");
+    else if constexpr (WPT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ws.v[0]), "+v"(ws.v[1]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ws.v[0]) : : "memory");
   };
-  auto wait_h = [&](int n, HItem& it) {
-    if constexpr (UP) {
-#define WM_TIE "+v"(it.v[0][0]), "+v"(it.v[0][1]), "+v"(it.v[1][0]), "+v"(it.v[1][1]), "+v"(it.v[2][0]), "+v"(it.v[2][1]), \
-               "+v"(it.v[UP ? 3 : 0][0]), "+v"(it.v[UP ? 3 : 0][1]), "+v"(it.t[0]), "+v"(it.t[1])
-      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
-#undef WM_TIE
-    } else {
-#define WM_TIE "+v"(it.v[0][0]), "+v"(it.v[0][1])
-      switch (n) { WM_VMW_ALL default: asm volatile("s_waitcnt vmcnt(0)" : WM_TIE : : "memory"); }
-#undef WM_TIE
-    }
+  auto wait_h = [&](int, HItem& it) {
+    if constexpr (UP)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(it.v[0][0]), "+v"(it.v[0][1]), "+v"(it.v[1][0]), "+v"(it.v[1][1]), "+v"(it.v[2][0]), "+v"(it.v[2][1]),
+                   "+v"(it.v[UP ? 3 : 0][0]), "+v"(it.v[UP ? 3 : 0][1]), "+v"(it.t[0]), "+v"(it.t[1]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(it.v[0][0]), "+v"(it.v[0][1]) : : "memory");
   };
-#undef WM_VMW_ALL
-#undef WM_VMW
   const int LI = UP ? (p.up_addx ? 10 : 8) : 2;  // loads per halo item
 
   f32x16 acc[TM][TN];
