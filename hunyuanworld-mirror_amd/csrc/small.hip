@@ -138,6 +138,61 @@ __global__ __launch_bounds__(256) void linear_f32_stream_kernel(const float* __r
   }
 }
 
+// Weight streaming on the fp32 MFMA (M <= 16 rows, N % 16 == 0, K % 64 == 0: every Linear of the camera trunk at up to
+// 16 views).  The VALU form above re-reads X for every pair of output columns (8 X loads per 2 W loads) and needs a
+// 64-lane reduction per (row, column); here a wave owns 16 output columns, its lanes hold W[n0 + l%16][k .. k+3] and
+// X[l%16][k .. k+3] (k = kb + 4 (l/16)) straight from 16-B loads, and four v_mfma_f32_16x16x4_f32 per 16 k's do the
+// dot products — exact fp32 FMA chains, no cross-lane reduction; the KW waves of a block split K and meet in LDS.
+template <int KW>
+__global__ __launch_bounds__(KW * 64) void linear_f32_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                                  const float* __restrict__ b, float* __restrict__ Y, int M, int N,
+                                                                  int K, int ldx, int ldy, int pre_act, int post_act,
+                                                                  const float* __restrict__ gamma, int accumulate) {
+  __shared__ float red[KW][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int kper = K / KW;  // K % (16 KW) == 0 (launcher)
+  const float* wp = W + (size_t)(n0 + lr) * K + wave * kper + 4 * lk;
+  const float* xp = X + (size_t)(lr < M ? lr : 0) * ldx + wave * kper + 4 * lk;
+  const bool xok = lr < M;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < kper; kb += 64) {  // 4 steps of 16 k's in flight
+    f32x4 wv[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wv[u] = *(const f32x4*)(wp + kb + 16 * u);
+      xv[u] = xok ? *(const f32x4*)(xp + kb + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pre_act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[u][e] = silu(xv[u][e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][e], wv[u][e], acc, 0, 0, 0);
+    }
+  }
+  // D[row m = 4 lk + r][col n = lr]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(4 * lk + r) * 16 + lr] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int m = tid >> 4, n = n0 + (tid & 15);
+    if (m < M) {
+      float v = b ? b[n] : 0.f;
+#pragma unroll
+      for (int w = 0; w < KW; ++w) v += red[w][tid];
+      if (post_act == 1) v = silu(v);
+      else if (post_act == 2) v = gelu_erf(v);
+      if (gamma) v *= gamma[n];
+      float* y = Y + (size_t)m * ldy + n;
+      *y = accumulate ? *y + v : v;
+    }
+  }
+}
+
 // softmax(q k^T / sqrt(hd)) v over S tokens; one wave per (head, query)
 __global__ __launch_bounds__(64) void small_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S,
                                                              int heads, int hd) {
@@ -235,6 +290,14 @@ hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, 
                                 int ldy, int pre_act, int post_act, const float* gamma, int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0) return hipSuccess;
   if (ldx % 4) return hipErrorInvalidValue;
+  if (M <= 16 && N % 16 == 0 && K % 1024 == 0 && wm_tuning[WM_TUNE_LIN_MFMA] != 0) {  // fp32-MFMA weight streaming
+    // waves per block (they split K) chosen so that the launch has ~2000 waves: N / 16 blocks alone would leave the
+    // 2048-column layers at 2 waves per CU
+    if (N <= 2048) hipLaunchKernelGGL((linear_f32_mfma_kernel<16>), dim3(N / 16), dim3(1024), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
+    else if (N <= 4096) hipLaunchKernelGGL((linear_f32_mfma_kernel<8>), dim3(N / 16), dim3(512), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
+    else hipLaunchKernelGGL((linear_f32_mfma_kernel<4>), dim3(N / 16), dim3(256), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
+    return hipGetLastError();
+  }
   if (K % 4 == 0 && K >= 256) {  // weight-streaming path
 #define WM_STREAM(MT)                                                                                              \
   hipLaunchKernelGGL((linear_f32_stream_kernel<MT, 4>), dim3((N + 3) / 4, (M + MT - 1) / MT), dim3(256), 0, s, X, W, b, Y, \
