@@ -1,4 +1,4 @@
 """MI355X-native WorldMirror forward pass (hand-written HIP kernels behind a C ABI)."""
 from .config import WMConfig, param_spec  # noqa: F401
 from .worldmirror import WorldMirror, extract_priors  # noqa: F401
-from .geometry import depth_to_world_coords_points  # noqa: F401
+from .geometry import create_confidence_mask, depth_to_world_coords_points  # noqa: F401

@@ -97,6 +97,8 @@ hipError_t wm_launch_add(const float* a, const float* b, float* out, size_t n, h
 // DPT tail: y32 f32 NHWC [n][H][W][32] (pre-ReLU) -> relu -> 1x1 (32->C) -> activation; writes attr [n][H][W][C-1], conf [n][H][W]
 hipError_t wm_launch_depth_to_world(const float* depth, const float* ext, const float* intr, float* world, float* cam,
                                     unsigned char* mask, int B, int H, int W, float eps, hipStream_t s);
+size_t wm_confidence_mask_workspace(size_t n);
+hipError_t wm_launch_confidence_mask(const float* conf, size_t n, unsigned int K, unsigned char* mask, void* workspace, hipStream_t s);
 hipError_t wm_launch_dpt_tail(const float* y32, const float* w, const float* b, float* attr, float* conf,
                               size_t npix, int C, int act, hipStream_t s);
 enum { WM_ACT_INV_LOG = 0, WM_ACT_EXP = 1, WM_ACT_NORM = 2 };

@@ -1288,6 +1288,18 @@ extern "C" wm_status wm_op_conv3x3_up(int dtype, const float* x, const void* w16
   if (getenv("WM_DBG_LATE")) a.relu_out = 7;
   return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
+extern "C" size_t wm_confidence_mask_workspace_bytes(size_t n) { return wm_confidence_mask_workspace(n); }
+extern "C" wm_status wm_confidence_mask(const float* conf, size_t n, float conf_threshold_percent, unsigned char* mask, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  if (!conf || !mask || !workspace || workspace_bytes < wm_confidence_mask_workspace(n)) return WM_ERR_INVALID;
+  if (n == 0) return WM_OK;
+  // infer.py:44-48: keep the top ceil(N (100 - p) / 100), at least one; p <= 0 keeps everything
+  double keep = (double)n;
+  if (conf_threshold_percent > 0.f) keep = std::ceil((double)n * (100.0 - (double)conf_threshold_percent) / 100.0);
+  size_t K = keep < 1.0 ? 1 : (size_t)keep;
+  if (K > n) K = n;
+  return wm_launch_confidence_mask(conf, n, (unsigned int)K, mask, workspace, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
 extern "C" wm_status wm_depth_to_world(const float* depth, const float* extrinsic, const float* intrinsic, float* world, float* cam,
                                        unsigned char* mask, int B, int H, int W, float eps, void* stream) {
   if (!depth || !extrinsic || !intrinsic || B < 0 || H < 0 || W < 0) return WM_ERR_INVALID;

@@ -32,3 +32,24 @@ def depth_to_world_coords_points(depth_map: Optional[torch.Tensor], extrinsic: t
     if _lib.lib().wm_depth_to_world(p(d), p(e), p(k), p(world), p(cam), p(mask), B, H, W, C.c_float(eps), s) != 0:
         raise RuntimeError("wm_depth_to_world failed")
     return world, cam, mask.bool()
+
+
+def create_confidence_mask(confidence: torch.Tensor, conf_threshold_percent: float = 30.0) -> torch.Tensor:
+    """Drop-in for infer.py:25-59: flat bool mask keeping the top (100 - p) % confidences (conf <= 1e-5 counts as
+    -inf).  Exact radix select on the GPU; ties at the threshold value go to the lowest indices."""
+    if confidence.device.type != "cuda":
+        raise RuntimeError("create_confidence_mask runs in libwm_hip.so: the tensor must be on the GPU")
+    c = confidence.contiguous().float().flatten()
+    n = c.numel()
+    mask = torch.empty(n, device=c.device, dtype=torch.uint8)
+    if n == 0:
+        return mask.bool()
+    L = _lib.lib()
+    wsb = L.wm_confidence_mask_workspace_bytes(n)
+    ws = torch.empty(wsb, device=c.device, dtype=torch.uint8)
+    s = C.c_void_p(torch.cuda.current_stream(c.device).cuda_stream)
+    if L.wm_confidence_mask(C.c_void_p(c.data_ptr()), n, C.c_float(conf_threshold_percent), C.c_void_p(mask.data_ptr()),
+                            C.c_void_p(ws.data_ptr()), wsb, s) != 0:
+        raise RuntimeError("wm_confidence_mask failed")
+    return mask.bool()
+

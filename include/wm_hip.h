@@ -145,6 +145,14 @@ wm_status wm_op_linear_f32(const float* X, const float* W, const float* b, float
 wm_status wm_depth_to_world(const float* depth, const float* extrinsic, const float* intrinsic, float* world, float* cam,
                             unsigned char* mask, int B, int H, int W, float eps, void* stream);
 
+/* create_confidence_mask (infer.py:25-59): mask[i] = 1 for the top ceil(n (100 - p) / 100) (at least 1; p <= 0: all)
+ * confidences after conf <= 1e-5 -> -inf; exact radix select on the device, ties at the threshold value broken by
+ * lowest index (the reference's torch.topk leaves them unspecified).  workspace: wm_confidence_mask_workspace_bytes(n)
+ * bytes of device memory.  n < 2^32. */
+size_t wm_confidence_mask_workspace_bytes(size_t n);
+wm_status wm_confidence_mask(const float* conf, size_t n, float conf_threshold_percent, unsigned char* mask, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* Process-wide kernel-selection override for tests and A/B tools (no reference counterpart).  key: "gemm_cfg"
  * (tile config id), "gemm_pp" (0/1 ping-pong GEMM), "gemm_mfma16" (0/1/2), "attn_qb" (attention variant);
  * value -1 restores the default.  Returns 0, or -1 for an unknown key. */

@@ -34,3 +34,24 @@ with torch.no_grad():
 out = os.path.join(ROOT, "tests", "golden", "geometry_depth_to_world.npz")
 np.savez_compressed(out, depth=depth, extrinsic=ext, intrinsic=K, world=world.numpy(), cam=cam.numpy(), mask=mask.numpy())
 print("wrote", out, os.path.getsize(out) // 1024, "KiB")
+
+# ---- create_confidence_mask (infer.py:25-59); infer.py itself imports heavy optional packages, so the function's
+# source text is executed from the file (build container only) instead of importing the module
+import ast, types  # noqa: E402
+src = open("/root/reference/infer.py").read()
+tree = ast.parse(src)
+fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "create_confidence_mask"][0]
+mod = types.ModuleType("ref_infer_part")
+mod.__dict__.update({"torch": torch, "np": np})
+exec(compile(ast.Module(body=[fn], type_ignores=[]), "/root/reference/infer.py", "exec"), mod.__dict__)
+conf = (1.0 + 9.0 * rng.random((2, 61, 47), dtype=np.float32)).astype(np.float32)   # continuous: no ties at the threshold
+conf[rng.random(conf.shape) < 0.1] = 0.0                                                # invalid (<= 1e-5 -> -inf), 10 % < the 30 % dropped
+store = {"conf": conf}
+for pct in (30.0, 0.0, 55.5, 99.99):
+    with torch.no_grad():
+        m = mod.create_confidence_mask(torch.from_numpy(conf), pct)
+    store[f"mask_{pct}"] = m.numpy()
+out2 = os.path.join(ROOT, "tests", "golden", "geometry_confidence_mask.npz")
+np.savez_compressed(out2, **store)
+print("wrote", out2, os.path.getsize(out2) // 1024, "KiB", {k: int(v.sum()) for k, v in store.items() if k != "conf"})
+

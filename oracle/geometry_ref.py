@@ -23,3 +23,18 @@ def depth_to_world_coords_points(depth_map, extrinsic, intrinsic, eps=1e-8):
     R, t = extrinsic[:, :3, :3], extrinsic[:, :3, 3]                        # :82-83
     world = np.einsum("bhwi,bji->bhwj", cam, R).astype(np.float32) + t[:, None, None, :]  # :86
     return world.astype(np.float32), cam, point_mask
+
+
+def create_confidence_mask(confidence, conf_threshold_percent=30.0):
+    """infer.py:25-59 restated in numpy.  Ties at the K-th value: lowest flat index first (stable sort) — the reference's
+    torch.topk leaves that choice unspecified, so fixtures are tie-free at the threshold."""
+    c = np.asarray(confidence, np.float32).reshape(-1).copy()
+    c[c <= 1e-5] = -np.inf                                   # :40
+    n = c.size
+    k = int(np.ceil(n * (100.0 - conf_threshold_percent) / 100.0)) if conf_threshold_percent > 0 else n   # :44-48
+    k = max(1, k)                                            # :49
+    order = np.argsort(-c, kind="stable")                    # top-k, lowest index first among equals (:52)
+    mask = np.zeros(n, bool)
+    mask[order[:k]] = True                                   # :55-56
+    return mask
+

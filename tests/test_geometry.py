@@ -84,3 +84,70 @@ def test_gpu_depth_to_world_full_size_and_bandwidth():
     w1, c1, k1 = depth_to_world_coords_points(d[:1, :5, :7].contiguous(), e[:1], k[:1])
     o1 = G.depth_to_world_coords_points(depth[:1, :5, :7].numpy(), ext[:1].numpy(), K[:1].numpy())
     assert np.array_equal(c1.cpu().numpy(), o1[1]) and rel_l2(w1.cpu().numpy(), o1[0]) < 1e-6
+
+
+# ------------------------------------------------------------------ create_confidence_mask (infer.py:25-59)
+def _gold_mask():
+    return np.load(os.path.join(GOLD, "geometry_confidence_mask.npz"))
+
+
+def test_oracle_confidence_mask_matches_reference():
+    z = _gold_mask()
+    for pct in (30.0, 0.0, 55.5, 99.99):
+        got = G.create_confidence_mask(z["conf"], pct)
+        assert got.shape == z[f"mask_{pct}"].shape
+        assert np.array_equal(got, z[f"mask_{pct}"]), pct
+
+
+@pytest.mark.gpu
+def test_gpu_confidence_mask_golden_and_edges():
+    from hunyuanworld_mirror_amd import create_confidence_mask
+    dev = torch.device("cuda:0")
+    z = _gold_mask()
+    conf = torch.from_numpy(z["conf"]).to(dev)
+    for pct in (30.0, 0.0, 55.5, 99.99):
+        m = create_confidence_mask(conf, pct)
+        assert m.dtype == torch.bool and m.shape == (conf.numel(),)
+        assert np.array_equal(m.cpu().numpy(), z[f"mask_{pct}"]), pct
+    # ties at the threshold, everything invalid, a single element, negative values, +inf and NaN: equal to the oracle
+    g = torch.Generator().manual_seed(0)
+    cases = {
+        "ties": torch.randint(0, 7, (10007,), generator=g).float(),
+        "all_invalid": torch.zeros(5000),
+        "single": torch.tensor([0.5]),
+        "mixed": torch.cat([torch.randn(3000, generator=g), torch.tensor([float("inf"), float("nan"), 1e-5, 2e-5])]),
+    }
+    for name, c in cases.items():
+        for pct in (30.0, 0.0, 80.0):
+            got = create_confidence_mask(c.to(dev), pct).cpu().numpy()
+            want = G.create_confidence_mask(c.numpy(), pct)
+            if name == "mixed":  # numpy's argsort puts NaN last, torch.topk (and the kernel) first: compare counts + ordering only
+                n = c.numel(); k = max(1, int(np.ceil(n * (100.0 - pct) / 100.0))) if pct > 0 else n
+                assert got.sum() == k
+                cm = c.clone(); cm[cm <= 1e-5] = -float("inf"); cm[torch.isnan(cm)] = float("inf")
+                assert cm.numpy()[got].min() >= cm.numpy()[~got].max() if (~got).any() else True
+            else:
+                assert np.array_equal(got, want), (name, pct)
+
+
+@pytest.mark.gpu
+def test_gpu_confidence_mask_full_size():
+    """8 x 518^2 confidences (BASELINE C2 output size): equals the oracle (sort-based), count exact; prints the time."""
+    from hunyuanworld_mirror_amd import create_confidence_mask
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    conf = 1.0 + torch.rand(8, 518, 518, generator=g) * 20
+    conf[torch.rand(8, 518, 518, generator=g) < 0.05] = 0
+    c = conf.to(dev)
+    m = create_confidence_mask(c, 30.0)
+    torch.cuda.synchronize()
+    want = G.create_confidence_mask(conf.numpy(), 30.0)
+    assert np.array_equal(m.cpu().numpy(), want)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        create_confidence_mask(c, 30.0)
+    e1.record(); torch.cuda.synchronize()
+    n = conf.numel()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    print(f"confidence mask {n} elements: {us:.0f} us incl. workspace allocation ({6 * 4 * n / (us * 1e-6) / 1e9:.0f} GB/s over its 6 read passes)")
