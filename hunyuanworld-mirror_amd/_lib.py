@@ -49,7 +49,8 @@ EXPORTS = [
     "wm_workspace_bytes", "wm_forward", "wm_forward_sharded", "wm_rccl_unique_id", "wm_comm_init_rccl",
     "wm_local_group_create", "wm_local_group_destroy", "wm_comm_init_local", "wm_profile_enable", "wm_profile_read",
     "wm_op_gemm", "wm_op_gemm_qkv", "wm_op_attention", "wm_op_layernorm", "wm_op_qkv_post", "wm_op_conv", "wm_op_bilinear",
-    "wm_op_linear_f32", "wm_host_to_16", "wm_set_tuning", "wm_op_attention_split", "wm_op_conv3x3_up", "wm_depth_to_world", "wm_confidence_mask", "wm_confidence_mask_workspace_bytes",
+    "wm_op_linear_f32", "wm_host_to_16", "wm_set_tuning", "wm_op_attention_split", "wm_op_conv3x3_up", "wm_depth_to_world", "wm_confidence_mask", "wm_confidence_mask_workspace_bytes", "wm_preprocess_image", "wm_preprocess_image_size",
+    "wm_preprocess_image_workspace_bytes",
 ]
 
 _lib = None
@@ -104,6 +105,12 @@ def lib() -> C.CDLL:
     L.wm_confidence_mask_workspace_bytes.restype = C.c_size_t
     L.wm_confidence_mask.argtypes = [vp, C.c_size_t, f32, vp, vp, C.c_size_t, vp]
     L.wm_confidence_mask.restype = i32
+    L.wm_preprocess_image_size.argtypes = [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.wm_preprocess_image_size.restype = i32
+    L.wm_preprocess_image_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.wm_preprocess_image_workspace_bytes.restype = C.c_size_t
+    L.wm_preprocess_image.argtypes = [vp, i32, i32, i32, i32, vp, vp, C.c_size_t, vp]
+    L.wm_preprocess_image.restype = i32
     L.wm_set_tuning.argtypes = [C.c_char_p, i32]
     L.wm_set_tuning.restype = i32
     _lib = L

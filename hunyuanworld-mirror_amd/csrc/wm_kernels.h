@@ -97,6 +97,10 @@ hipError_t wm_launch_add(const float* a, const float* b, float* out, size_t n, h
 // DPT tail: y32 f32 NHWC [n][H][W][32] (pre-ReLU) -> relu -> 1x1 (32->C) -> activation; writes attr [n][H][W][C-1], conf [n][H][W]
 hipError_t wm_launch_depth_to_world(const float* depth, const float* ext, const float* intr, float* world, float* cam,
                                     unsigned char* mask, int B, int H, int W, float eps, hipStream_t s);
+hipError_t wm_launch_resample_h(const unsigned char* in, unsigned char* out, int H, int Wi, int Wo, const int* bounds, const int* kk,
+                                int ksize, hipStream_t s);
+hipError_t wm_launch_resample_v_tensor(const unsigned char* tmp, float* out, int Hi, int W, int Ho, int Hf, int Wf, int ry0, int rx0,
+                                       const int* bounds, const int* kk, int ksize, hipStream_t s);
 size_t wm_confidence_mask_workspace(size_t n);
 hipError_t wm_launch_confidence_mask(const float* conf, size_t n, unsigned int K, unsigned char* mask, void* workspace, hipStream_t s);
 hipError_t wm_launch_dpt_tail(const float* y32, const float* w, const float* b, float* attr, float* conf,

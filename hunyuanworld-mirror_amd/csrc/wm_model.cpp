@@ -1288,6 +1288,117 @@ extern "C" wm_status wm_op_conv3x3_up(int dtype, const float* x, const void* w16
   if (getenv("WM_DBG_LATE")) a.relu_out = 7;
   return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
+// ---------------------------------------------------------------- image ingest
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc (libImaging/Resample.c) for the BICUBIC filter, in double
+// precision with contraction off so that every rounding matches Pillow's C build (and oracle/ingest_ref.py).
+#pragma clang fp contract(off)
+static double wm_bicubic(double x) {
+  const double a = -0.5;
+  if (x < 0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+static int wm_resample_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk) {
+#pragma clang fp contract(off)
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 2.0 * filterscale;
+  const int ksize = (int)std::ceil(support) * 2 + 1;
+  bounds.assign((size_t)out_size * 2, 0);
+  kk.assign((size_t)out_size * ksize, 0);
+  std::vector<double> w((size_t)ksize);
+  const double ss = 1.0 / filterscale;
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      w[x] = wm_bicubic((x + xmin - center + 0.5) * ss);
+      ww += w[x];
+    }
+    for (int x = 0; x < xmax; ++x) {
+      double v = w[x];
+      if (ww != 0.0) v /= ww;
+      kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << 22)) : (int)(0.5 + v * (double)(1 << 22));
+    }
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+  }
+  return ksize;
+}
+// inference_utils.py:70-83; Python's round() is half-to-even = nearbyint in the default rounding mode
+static void wm_ingest_dims(int H, int W, int mode, int target, int* sw, int* sh, int* hf, int* wf, int* ry0, int* rx0) {
+#pragma clang fp contract(off)
+  if (mode == 1) {  // pad
+    if (W >= H) { *sw = target; *sh = (int)std::nearbyint((double)H * ((double)target / (double)W) / 14.0) * 14; }
+    else { *sh = target; *sw = (int)std::nearbyint((double)W * ((double)target / (double)H) / 14.0) * 14; }
+    *hf = target > *sh ? target : *sh; *wf = target > *sw ? target : *sw;           // pad up to the square; never crops
+    *ry0 = -((*hf - *sh) / 2); *rx0 = -((*wf - *sw) / 2);
+  } else {          // crop
+    *sw = target; *sh = (int)std::nearbyint((double)H * ((double)target / (double)W) / 14.0) * 14;
+    *wf = *sw; *hf = *sh > target ? target : *sh;
+    *ry0 = *sh > target ? (*sh - target) / 2 : 0; *rx0 = 0;
+  }
+}
+extern "C" wm_status wm_preprocess_image_size(int H, int W, int mode, int output_size, int* out_h, int* out_w) {
+  if (H <= 0 || W <= 0 || (mode != 0 && mode != 1) || output_size <= 0 || !out_h || !out_w) return WM_ERR_INVALID;
+  int sw, sh, ry0, rx0;
+  wm_ingest_dims(H, W, mode, output_size, &sw, &sh, out_h, out_w, &ry0, &rx0);
+  return (sw > 0 && sh > 0) ? WM_OK : WM_ERR_INVALID;
+}
+extern "C" size_t wm_preprocess_image_workspace_bytes(int H, int W, int mode, int output_size) {
+  int sw, sh, hf, wf, ry0, rx0;
+  if (H <= 0 || W <= 0) return 0;
+  wm_ingest_dims(H, W, mode, output_size, &sw, &sh, &hf, &wf, &ry0, &rx0);
+  if (sw <= 0 || sh <= 0) return 0;
+  auto ks = [](int in, int out) { const double sc = (double)in / out; return (int)std::ceil(2.0 * (sc < 1.0 ? 1.0 : sc)) * 2 + 1; };
+  const size_t tabs = ((size_t)sw * (2 + ks(W, sw)) + (size_t)sh * (2 + ks(H, sh))) * sizeof(int);
+  return (size_t)H * sw * 3 + 256 + tabs + 256;
+}
+extern "C" wm_status wm_preprocess_image(const unsigned char* rgb, int H, int W, int mode, int output_size, float* out, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!rgb || !out || !workspace || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return WM_ERR_INVALID;
+  if (workspace_bytes < wm_preprocess_image_workspace_bytes(H, W, mode, output_size)) return WM_ERR_INVALID;
+  int sw, sh, hf, wf, ry0, rx0;
+  wm_ingest_dims(H, W, mode, output_size, &sw, &sh, &hf, &wf, &ry0, &rx0);
+  if (sw <= 0 || sh <= 0) return WM_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int> bh, kh, bv, kv;
+  const int ksh = sw != W ? wm_resample_coeffs(W, sw, bh, kh) : 0;
+  const int ksv = sh != H ? wm_resample_coeffs(H, sh, bv, kv) : 0;
+  char* ws = (char*)workspace;
+  unsigned char* tmp = (unsigned char*)ws;
+  size_t off = ((size_t)H * sw * 3 + 255) / 256 * 256;
+  int* d_bh = (int*)(ws + off); off += bh.size() * 4;
+  int* d_kh = (int*)(ws + off); off += kh.size() * 4;
+  int* d_bv = (int*)(ws + off); off += bv.size() * 4;
+  int* d_kv = (int*)(ws + off); off += kv.size() * 4;
+  // the tables are small (a few hundred KB at most); pageable copies are synchronous with respect to the host, which
+  // keeps the vectors alive long enough
+  if (ksh) {
+    if (hipMemcpyAsync(d_bh, bh.data(), bh.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return WM_ERR_HIP;
+    if (hipMemcpyAsync(d_kh, kh.data(), kh.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return WM_ERR_HIP;
+  }
+  if (ksv) {
+    if (hipMemcpyAsync(d_bv, bv.data(), bv.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return WM_ERR_HIP;
+    if (hipMemcpyAsync(d_kv, kv.data(), kv.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return WM_ERR_HIP;
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return WM_ERR_HIP;
+  const unsigned char* hsrc = rgb;
+  if (ksh) {
+    if (wm_launch_resample_h(rgb, tmp, H, W, sw, d_bh, d_kh, ksh, s) != hipSuccess) return WM_ERR_HIP;
+    hsrc = tmp;
+  }
+  if (wm_launch_resample_v_tensor(hsrc, out, H, sw, sh, hf, wf, ry0, rx0, ksv ? d_bv : nullptr, ksv ? d_kv : nullptr, ksv, s) != hipSuccess)
+    return WM_ERR_HIP;
+  return WM_OK;
+}
+
 extern "C" size_t wm_confidence_mask_workspace_bytes(size_t n) { return wm_confidence_mask_workspace(n); }
 extern "C" wm_status wm_confidence_mask(const float* conf, size_t n, float conf_threshold_percent, unsigned char* mask, void* workspace,
                                         size_t workspace_bytes, void* stream) {

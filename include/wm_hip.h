@@ -145,6 +145,17 @@ wm_status wm_op_linear_f32(const float* X, const float* W, const float* b, float
 wm_status wm_depth_to_world(const float* depth, const float* extrinsic, const float* intrinsic, float* world, float* cam,
                             unsigned char* mask, int B, int H, int W, float eps, void* stream);
 
+/* ---- image ingest after decode ----
+ * load_and_preprocess_images (src/utils/inference_utils.py:67-108) for ONE decoded image: rgb [H][W][3] uint8 (device)
+ * -> Pillow-exact BICUBIC resize to (518, round(H*518/W/14)*14) ["crop", mode 0] or the longer side to 518 ["pad",
+ * mode 1] -> /255 -> centre crop of the height / white padding to the square -> out planar float32 [3][out_h][out_w]
+ * (device; sizes from wm_preprocess_image_size).  Decoding, alpha compositing and stacking stay on the host side of
+ * the binding.  workspace: wm_preprocess_image_workspace_bytes bytes of device memory. */
+wm_status wm_preprocess_image_size(int H, int W, int mode, int output_size, int* out_h, int* out_w);
+size_t wm_preprocess_image_workspace_bytes(int H, int W, int mode, int output_size);
+wm_status wm_preprocess_image(const unsigned char* rgb, int H, int W, int mode, int output_size, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* create_confidence_mask (infer.py:25-59): mask[i] = 1 for the top ceil(n (100 - p) / 100) (at least 1; p <= 0: all)
  * confidences after conf <= 1e-5 -> -inf; exact radix select on the device, ties at the threshold value broken by
  * lowest index (the reference's torch.topk leaves them unspecified).  workspace: wm_confidence_mask_workspace_bytes(n)
