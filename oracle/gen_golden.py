@@ -176,8 +176,14 @@ def main():
     ap.add_argument("--full", action="store_true", help="also run the full-size 2x224 case (config C1)")
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--refinit", action="store_true", help="goldens with the reference's own init statistics")
+    ap.add_argument("--full-priors", action="store_true", help="full architecture, 2 x 224^2, pose + intrinsics priors (the C3 flag set)")
     a = ap.parse_args()
     torch.manual_seed(0)
+    if a.full_priors:
+        cfg = WMConfig()
+        m = build_reference(cfg)
+        run_case(m, cfg, "full_2v_224_pose_ray", 12, 2, 224, 224, [1, 0, 1], sub=4, keep_taps=False)
+        return
     if a.refinit:
         cfg = WMConfig.tiny()
         m = build_reference(cfg, "refinit")

@@ -82,11 +82,12 @@ def test_tiny_golden_f16_backbone():
         assert e < TOL_F16[k]
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "full_2v_224_noprior.npz")), reason="fixture missing")
-def test_full_arch_2x224_golden():
-    """BASELINE config C1: the full 1.23 B-parameter architecture, 2 x 224^2, against the reference's outputs."""
-    cfg, views, flags, outs, z = load_golden("full_2v_224_noprior")
-    m = _model(cfg)
+@pytest.mark.parametrize("name", ["full_2v_224_noprior", "full_2v_224_pose_ray"])
+def test_full_arch_2x224_golden(name):
+    """The full 1.23 B-parameter architecture, 2 x 224^2, against the reference's outputs: BASELINE config C1
+    (no priors) and the C3 flag set (camera-pose + intrinsics priors on)."""
+    cfg, views, flags, outs, z = load_golden(name)
+    m = _cached_model(cfg)
     got = _run(m, views, flags)
     sub = int(z["subsample"])
     errs = {}
@@ -96,7 +97,7 @@ def test_full_arch_2x224_golden():
             g = g[:, :, ::sub, ::sub]
         assert g.shape == v.shape, k
         errs[k] = rel_l2(g, v)
-    print("full_2v_224", {k: f"{e:.2e}" for k, e in errs.items()})
+    print(name, {k: f"{e:.2e}" for k, e in errs.items()})
     for k, tol in TOL.items():
         assert errs[k] < tol, (k, errs[k])
     # checksum-of-everything property at full resolution (not just the subsampled pixels)

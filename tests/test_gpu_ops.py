@@ -409,7 +409,9 @@ def test_bilinear(dev):
         assert _rel(y, ref) < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K,ldx", [(3, 256, 9, 12), (12, 512, 256, 256), (64, 6144, 2048, 2048), (5, 9, 1024, 1024)])
+# the last four shapes take the fp32-MFMA weight-streaming kernel (M <= 16, N % 16 == 0, K % 1024 == 0): 4, 8 and 16 waves per block
+@pytest.mark.parametrize("M,N,K,ldx", [(3, 256, 9, 12), (12, 512, 256, 256), (64, 6144, 2048, 2048), (5, 9, 1024, 1024),
+                                       (8, 6144, 2048, 2048), (13, 2048, 2048, 2080), (16, 4096, 1024, 1024), (1, 2048, 8192, 8192)])
 def test_linear_f32(dev, M, N, K, ldx):
     g = torch.Generator().manual_seed(M + N)
     X = torch.zeros(M, ldx)

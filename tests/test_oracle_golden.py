@@ -76,12 +76,12 @@ def test_prune_gs_merges_voxels():
     assert torch.allclose(out["opacities"], torch.tensor([(1 + 9) / 4.0, 4 / 2.0]))
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "full_2v_224_noprior.npz")),
-                    reason="full-size fixture not generated")
 @pytest.mark.skipif(os.environ.get("WM_SKIP_FULL_ORACLE") == "1", reason="skipped by env")
-def test_oracle_matches_reference_full_2x224():
-    """BASELINE config C1 (2 x 224^2, full 1.23 B-parameter architecture)."""
-    cfg, o, outs, z, col = _run("full_2v_224_noprior")
+@pytest.mark.parametrize("name", ["full_2v_224_noprior", "full_2v_224_pose_ray"])
+def test_oracle_matches_reference_full_2x224(name):
+    """Full 1.23 B-parameter architecture at 2 x 224^2: BASELINE config C1 (no priors) and the C3 flag set
+    (camera-pose + intrinsics priors on, cond_flags [1, 0, 1])."""
+    cfg, o, outs, z, col = _run(name)
     sub = int(z["subsample"])
     for k, v in outs.items():
         got = o[k].numpy()
