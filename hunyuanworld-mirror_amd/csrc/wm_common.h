@@ -86,6 +86,15 @@ __device__ __forceinline__ void xhalf_pair(float x, float& a, float& b) {
 __device__ __forceinline__ float xhalf_max(float x) { float a, b; xhalf_pair(x, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float xhalf_sum(float x) { float a, b; xhalf_pair(x, a, b); return a + b; }
 
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second.  With
+// a = this lane's packed columns of sub-tile j0 and b = those of sub-tile j1 (MFMA 16x16 D layout: lane = (row l15,
+// quad lq) owns 4 consecutive columns), afterwards an even-lq lane holds {a, b} = 8 consecutive columns of j0
+// (its own 4 + those of lq + 1) and an odd-lq lane 8 consecutive columns of j1 (those of lq - 1 + its own): 16-B
+// stores of 64-B row segments instead of 8-B stores of 32-B segments.  Every lane of the wave must be active.
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 // XCD-aware bijective block remap (guides T1): blocks b and b+8 share an XCD; give each XCD a
 // contiguous chunk of the logical tile space so neighbouring tiles hit the same L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
