@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--views-per-gpu", type=int, default=8)
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--priors", action="store_true",
+                    help="camera-pose + intrinsics priors on (BASELINE config C3: --views-per-gpu 32 --priors), cond_flags [1, 0, 1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="scaled-down architecture (plumbing check only)")
     a = ap.parse_args()
@@ -116,6 +118,15 @@ def main():
         m.shard()
     g = torch.Generator().manual_seed(1234)
     views = {"img": torch.rand(1, n_total, 3, H, W, generator=g).to(dev)}
+    flags = [0, 0, 0]
+    if a.priors:  # SURVEY §8d synthetic priors: identity rotations, x = 0.1 i, fx = fy = W, principal point at the centre
+        pose = torch.eye(4).repeat(1, n_total, 1, 1)
+        pose[0, :, 0, 3] = 0.1 * torch.arange(n_total)
+        K = torch.zeros(1, n_total, 3, 3)
+        K[..., 0, 0] = W; K[..., 1, 1] = H; K[..., 0, 2] = W / 2; K[..., 1, 2] = H / 2; K[..., 2, 2] = 1
+        views["camera_pose"] = pose.to(dev)
+        views["camera_intrinsics"] = K.to(dev)
+        flags = [1, 0, 1]
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -124,13 +135,13 @@ def main():
             torch.cuda.synchronize(dev)
 
     for i in range(a.warmup):
-        m(views)
+        m(views, flags)
         torch.cuda.synchronize(dev)
         log(f"warmup {i} done")
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        m(views)
+        m(views, flags)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -142,7 +153,7 @@ def main():
 
     # per-kernel-class timing: HIP events recorded by the library on the launch stream (one extra step)
     m.profile(True)
-    m(views)
+    m(views, flags)
     torch.cuda.synchronize(dev)
     fl = flop_model(cfg, n_local, n_total, H, W)
     classes = {}
@@ -173,7 +184,7 @@ def main():
         line = {"metric": "views/sec", "value": round(n_total / (ms_step * 1e-3), 3), "unit": "views/s", "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-                "config": {"workload": f"{n_total}-view {H}x{W} {a.dtype}, no priors, camera+depth+pointmap+normal heads, "
+                "config": {"workload": f"{n_total}-view {H}x{W} {a.dtype}, {'camera-pose + intrinsics priors' if a.priors else 'no priors'}, camera+depth+pointmap+normal heads, "
                                        f"{n_local} views/GPU" + (", tiny arch" if a.tiny else ", full 1.23B-param arch"),
                            "views_per_gpu": n_local, "global_views": n_total, "parallelism": f"view-shard x{world}"},
                 "roofline": roof}

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
           for (int g = 0; g < 4; ++g) {
             if (!ok[g]) continue;
             float4 x = v[g];
-            if constexpr (EPI == WM_EPI_GELU_T16) x = make_float4(gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w));
+            if constexpr (EPI == WM_EPI_GELU_T16) x = gelu_erf4(x);
             uint2 u;
             u.x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
             u.y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
@@ -380,15 +380,40 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
     const bool do_norm = which < 2 && nw != nullptr, do_rope = which < 2 && q.rope_cos != nullptr;
     u16* dst = (u16*)(which == 0 ? q.q : which == 1 ? q.k : q.v);
     const float sc = which == 0 ? q.q_scale : 1.0f;
+    // column vectors of this head are the same for every row group: loaded once.  The per-row RoPE table rows are
+    // requested one row group ahead, i.e. BEFORE the previous group's stores (the compiler may not move a load across
+    // a possibly aliasing store, so loads placed after them would each pay a full L2 round trip per row group).
+    float4 bs4[4], w4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bs4[j] = p.bias ? *(const float4*)(p.bias + col0 + 16 * j + 4 * lq) : make_float4(0, 0, 0, 0);
+      w4[j] = do_norm ? *(const float4*)(nw + 16 * j + 4 * lq) : make_float4(1, 1, 1, 1);
+      b4[j] = do_norm ? *(const float4*)(nb + 16 * j + 4 * lq) : make_float4(0, 0, 0, 0);
+    }
+    auto rope_rows = [&](int i, float4 (&cs)[2], float4 (&sn)[2]) {
+      const int row = rowb + i * 16 + l15;
+      const int rr = row < p.M ? row : 0;
+      const int t = rr - (int)(((float)rr + 0.5f) * q.inv_tpv) * q.tokens_per_view;  // see gemm_nt_kernel
+      int py = 0, px = 0;
+      if (t >= q.patch_start) {
+        const int idx = t - q.patch_start;
+        py = (int)(((float)idx + 0.5f) * q.inv_gw) + 1;
+        px = idx - (py - 1) * q.grid_w + 1;
+      }
+      cs[0] = *(const float4*)(q.rope_cos + py * 16 + 4 * lq); sn[0] = *(const float4*)(q.rope_sin + py * 16 + 4 * lq);
+      cs[1] = *(const float4*)(q.rope_cos + px * 16 + 4 * lq); sn[1] = *(const float4*)(q.rope_sin + px * 16 + 4 * lq);
+    };
+    float4 csn[2][2], snn[2][2];  // [parity of the row group][y | x]
+    if (do_rope) rope_rows(0, csn[0], snn[0]);
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
       const int row = rowb + i * 16 + l15;
       const bool row_ok = row < p.M;
+      if (do_rope && i + 1 < SM) rope_rows(i + 1, csn[(i + 1) & 1], snn[(i + 1) & 1]);
       float v[4][4];  // [j: 16-col group][e]: column 16j + 4*lq + e of this head
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 bs = p.bias ? *(const float4*)(p.bias + col0 + 16 * j + 4 * lq) : make_float4(0, 0, 0, 0);
-        v[j][0] = acc[i][j][0] + bs.x; v[j][1] = acc[i][j][1] + bs.y; v[j][2] = acc[i][j][2] + bs.z; v[j][3] = acc[i][j][3] + bs.w;
+        v[j][0] = acc[i][j][0] + bs4[j].x; v[j][1] = acc[i][j][1] + bs4[j].y; v[j][2] = acc[i][j][2] + bs4[j].z; v[j][3] = acc[i][j][3] + bs4[j].w;
       }
       if (do_norm) {  // the row's 64 values live in the 4 lanes l15 + 16*{0..3}
         float sm = 0.f;
@@ -407,25 +432,14 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
         const float rstd = 1.0f / sqrtf(xhalf_sum(ss) * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 w4 = *(const float4*)(nw + 16 * j + 4 * lq), b4 = *(const float4*)(nb + 16 * j + 4 * lq);
-          v[j][0] = v[j][0] * rstd * w4.x + b4.x; v[j][1] = v[j][1] * rstd * w4.y + b4.y;
-          v[j][2] = v[j][2] * rstd * w4.z + b4.z; v[j][3] = v[j][3] * rstd * w4.w + b4.w;
+          v[j][0] = v[j][0] * rstd * w4[j].x + b4[j].x; v[j][1] = v[j][1] * rstd * w4[j].y + b4[j].y;
+          v[j][2] = v[j][2] * rstd * w4[j].z + b4[j].z; v[j][3] = v[j][3] * rstd * w4[j].w + b4[j].w;
         }
       }
       if (do_rope) {
-        const int rr = row_ok ? row : 0;
-        const int t = rr - (int)(((float)rr + 0.5f) * q.inv_tpv) * q.tokens_per_view;  // see gemm_nt_kernel
-        int py = 0, px = 0;
-        if (t >= q.patch_start) {
-          const int idx = t - q.patch_start;
-          py = (int)(((float)idx + 0.5f) * q.inv_gw) + 1;
-          px = idx - (py - 1) * q.grid_w + 1;
-        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {  // columns [0,32) rotate by y, [32,64) by x; pair (c, c+16) = groups (2hh, 2hh+1)
-          const int pos = hh == 0 ? py : px;
-          const float4 cs = *(const float4*)(q.rope_cos + pos * 16 + 4 * lq);
-          const float4 sn = *(const float4*)(q.rope_sin + pos * 16 + 4 * lq);
+          const float4 cs = csn[i & 1][hh], sn = snn[i & 1][hh];
           const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -469,7 +483,7 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
               const int j = 2 * jp + h, col = colb + j * 16 + 4 * lq;
               const float4 bs = (p.bias && col < p.N) ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
               float4 x = make_float4(acc[i][j][0] + bs.x, acc[i][j][1] + bs.y, acc[i][j][2] + bs.z, acc[i][j][3] + bs.w);
-              if constexpr (EPI == WM_EPI_GELU_T16) x = make_float4(gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w));
+              if constexpr (EPI == WM_EPI_GELU_T16) x = gelu_erf4(x);
               u[h].x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
               u[h].y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
             }
@@ -496,7 +510,7 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
         if constexpr (EPI == WM_EPI_F32) {
           *(float4*)((float*)p.C + o) = x;
         } else if constexpr (EPI == WM_EPI_T16 || EPI == WM_EPI_GELU_T16) {
-          if constexpr (EPI == WM_EPI_GELU_T16) x = make_float4(gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w));
+          if constexpr (EPI == WM_EPI_GELU_T16) x = gelu_erf4(x);
           uint2 u;
           u.x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
           u.y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);

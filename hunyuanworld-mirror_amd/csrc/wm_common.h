@@ -64,6 +64,29 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
+// The same GELU on two values at a time with packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: 7.5 full-rate VALU per element
+// instead of ~17): s = |x| / sqrt 2 is folded into the constants, and with hx = x / 2, pte = p t exp(-x^2 / 2)
+//   gelu = hx (1 + sign(x) (1 - pte)) = (hx + |hx|) - |hx| pte        (no cancellation for x < 0: hx + |hx| = 0 exactly)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  auto k = [](float c) { return f32x2_t{c, c}; };
+  const f32x2_t ax = __builtin_elementwise_abs(x);
+  const f32x2_t d = __builtin_elementwise_fma(ax, k(0.3275911f * 0.70710678118654752440f), k(1.0f));
+  const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2_t p = __builtin_elementwise_fma(t, k(1.061405429f), k(-1.453152027f));
+  p = __builtin_elementwise_fma(p, t, k(1.421413741f));
+  p = __builtin_elementwise_fma(p, t, k(-0.284496736f));
+  p = __builtin_elementwise_fma(p, t, k(0.254829592f));
+  const f32x2_t q = x * x * k(-0.5f * 1.4426950408889634f);
+  const f32x2_t e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  const f32x2_t hx = x * k(0.5f), ah = ax * k(0.5f);
+  return __builtin_elementwise_fma(-ah, p * t * e, hx + ah);
+}
+__device__ __forceinline__ float4 gelu_erf4(float4 x) {
+  const f32x2_t a = gelu_erf2(f32x2_t{x.x, x.y}), b = gelu_erf2(f32x2_t{x.z, x.w});
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
