@@ -469,6 +469,15 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
     }
     return;
   } else {
+    // Column vectors (bias, LayerScale gamma) depend on j only: loaded once, ahead of every store (the compiler may not
+    // move a load across a possibly aliasing store, so a load inside the (i, j) loop pays its latency per iteration).
+    float4 bs4[SN], gm4[SN];
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+      const int col = colb + j * 16 + 4 * lq;
+      bs4[j] = (p.bias && col < p.N) ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
+      if constexpr (EPI == WM_EPI_RESID) gm4[j] = col < p.N ? *(const float4*)(p.gamma + col) : make_float4(0, 0, 0, 0);
+    }
     if constexpr ((EPI == WM_EPI_T16 || EPI == WM_EPI_GELU_T16) && SN % 2 == 0) {
       // 16-bit outputs: pair the sub-tiles (2jp, 2jp + 1) through swap16 and store 16 B per lane
       if ((p.N & 7) == 0 && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0) {
@@ -480,9 +489,8 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
             uint2 u[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const int j = 2 * jp + h, col = colb + j * 16 + 4 * lq;
-              const float4 bs = (p.bias && col < p.N) ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
-              float4 x = make_float4(acc[i][j][0] + bs.x, acc[i][j][1] + bs.y, acc[i][j][2] + bs.z, acc[i][j][3] + bs.w);
+              const int j = 2 * jp + h;
+              float4 x = make_float4(acc[i][j][0] + bs4[j].x, acc[i][j][1] + bs4[j].y, acc[i][j][2] + bs4[j].z, acc[i][j][3] + bs4[j].w);
               if constexpr (EPI == WM_EPI_GELU_T16) x = gelu_erf4(x);
               u[h].x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
               u[h].y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
@@ -496,6 +504,33 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
         return;
       }
     }
+    if constexpr (EPI == WM_EPI_RESID) {
+      // in-place X += gamma * (acc + bias): the old values of row group i + 1 are requested before row group i is stored
+      float4 old[2][SN];
+      auto load_old = [&](int i, float4 (&o)[SN]) {
+        const int row = rowb + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < SN; ++j) {
+          const int col = colb + j * 16 + 4 * lq;
+          o[j] = (row < p.M && col < p.N) ? *(const float4*)((const float*)p.C + (size_t)row * p.ldc + col) : make_float4(0, 0, 0, 0);
+        }
+      };
+      load_old(0, old[0]);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        if (i + 1 < SM) load_old(i + 1, old[(i + 1) & 1]);
+        const int row = rowb + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < SN; ++j) {
+          const int col = colb + j * 16 + 4 * lq;
+          const float4 o = old[i & 1][j], gm = gm4[j], bs = bs4[j];
+          if (row < p.M && col < p.N)
+            *(float4*)((float*)p.C + (size_t)row * p.ldc + col) =
+                make_float4(o.x + gm.x * (acc[i][j][0] + bs.x), o.y + gm.y * (acc[i][j][1] + bs.y), o.z + gm.z * (acc[i][j][2] + bs.z), o.w + gm.w * (acc[i][j][3] + bs.w));
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
       const int row = rowb + i * 16 + l15;
@@ -504,7 +539,7 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
       for (int j = 0; j < SN; ++j) {
         const int col = colb + j * 16 + 4 * lq;
         if (col >= p.N) continue;
-        const float4 bs = p.bias ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
+        const float4 bs = bs4[j];
         float4 x = make_float4(acc[i][j][0] + bs.x, acc[i][j][1] + bs.y, acc[i][j][2] + bs.z, acc[i][j][3] + bs.w);
         const size_t o = (size_t)row * p.ldc + col;
         if constexpr (EPI == WM_EPI_F32) {
@@ -515,10 +550,6 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
           u.x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
           u.y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
           *(uint2*)((u16*)p.C + o) = u;
-        } else if constexpr (EPI == WM_EPI_RESID) {
-          const float4 old = *(const float4*)((const float*)p.C + o);
-          const float4 gm = *(const float4*)(p.gamma + col);
-          *(float4*)((float*)p.C + o) = make_float4(old.x + gm.x * x.x, old.y + gm.y * x.y, old.z + gm.z * x.z, old.w + gm.w * x.w);
         }
       }
     }
