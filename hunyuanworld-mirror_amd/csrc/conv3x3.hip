@@ -320,8 +320,13 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const WmConvArgs p) {
 // to LDS at the end of tap kt+1 (two taps of flight), a halo item of the next chunk is requested at the top of a tap
 // and written at the end of the next one, and the tap barrier is a raw s_barrier behind an lgkmcnt(0) (a
 // __syncthreads() would drain the loads in flight).
-template <int T, int WM, int WN, int TM, int TN, int UP = 0>
+// TPX x (256 / TPX) output pixels per block: 16 x 16, or 32 wide x 8 high where that needs fewer rounds over the CUs
+// (148^2 at 8 views: 800 tiles = 3.1 rounds with 16 x 16, 760 = 2.97 with 32 x 8).
+template <int T, int WM, int WN, int TM, int TN, int UP = 0, int TPX = 16>
 __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
+  constexpr int TPY = 256 / TPX, LGX = TPX == 16 ? 4 : 5;
+  static_assert(TPX == 16 || TPX == 32, "pixel tile 16 x 16 or 32 x 8");
+  constexpr int HWX = TPX + 2, HWY = TPY + 2, HROWS = HWX * HWY, HALO_BYTES = HROWS * 128, HCH = HROWS * 8, HPT = (HCH + 511) / 512;
   constexpr int BN = WN * TN * 32;
   constexpr int B_BYTES = BN * 128;
   constexpr int WPT = BN * 8 / 512;  // 16-B weight chunks per thread per tap: 4 (256 ch) or 2 (128 ch)
@@ -333,14 +338,14 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int H = p.Hi, W = p.Wi, Cin = p.Cin, Cout = p.Cout;
-  const int tiles_x = (W + TP - 1) / TP, tiles_y = (H + TP - 1) / TP, ctiles = (Cout + BN - 1) / BN;
+  const int tiles_x = (W + TPX - 1) / TPX, tiles_y = (H + TPY - 1) / TPY, ctiles = (Cout + BN - 1) / BN;
   const int nblk = p.N * tiles_y * tiles_x * ctiles;
   int lid = xcd_remap(blockIdx.x, nblk);
   const int ct = lid % ctiles; lid /= ctiles;
   const int tx = lid % tiles_x; lid /= tiles_x;
   const int ty = lid % tiles_y;
   const int n = lid / tiles_y;
-  const int y0 = ty * TP, x0 = tx * TP, n0 = ct * BN;
+  const int y0 = ty * TPY, x0 = tx * TPX, n0 = ct * BN;
   const float* xin = UP ? p.x + (size_t)n * p.up_hs * p.up_ws * Cin : p.x + (size_t)n * H * W * Cin;
   const float usy = UP && H > 1 ? (float)(p.up_hs - 1) / (float)(H - 1) : 0.f;
   const float usx = UP && W > 1 ? (float)(p.up_ws - 1) / (float)(W - 1) : 0.f;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
   auto h_load = [&](int cc, int i, HItem& it) {
     const int id = tid + i * 512;
     const int hr = id >> 3, ch = id & 7;
-    const int hy = hr / HW_, hx = hr - hy * HW_;
+    const int hy = hr / HWX, hx = hr - hy * HWX;
     const int iy = y0 + hy - 1, ix = x0 + hx - 1;
     it.in = id < HCH && iy >= 0 && iy < H && ix >= 0 && ix < W;
     const int c0 = cc * 64 + ch * 8;
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = (wm * TM + i) * 32 + (lane & 31);
-    hbase[i] = (r >> 4) * HW_ + (r & 15);
+    hbase[i] = (r >> LGX) * HWX + (r & (TPX - 1));
   }
 
   // ---- prologue: weights(0) and (1) requested, chunk 0's halo staged, weights(0) written
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     if (kt + 2 < NT) w_load(kt + 2, w_mine);
     if (more_chunks && tap < HPT) h_load(cc + 1, tap, h_mine);
     const char* tB = bbuf + PAR * B_BYTES;
-    const int toff = (tap / 3) * HW_ + (tap % 3);
+    const int toff = (tap / 3) * HWX + (tap % 3);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int ch = 2 * ks + (lane >> 5);
@@ -558,53 +563,72 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     }
   }
 
-  // ---- epilogue (same as conv3x3_kernel)
+  // ---- epilogue: lane = pixel (lane & 31) of tile i, regs 4g..4g+3 <-> channels 8g + 4h + {0..3}.  The bias vectors depend
+  // on (j, g) only and are loaded once; the residual inputs of the next (i, j) group are requested before this group's
+  // stores (the compiler may not move a load across a possibly aliasing store: loads inside the innermost loop would pay
+  // an L2 / HBM round trip per 16-B store).
   const int h4 = (lane >> 5) * 4;
+  float4 bs[TN][4];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = n0 + (wn * TN + j) * 32 + h4 + 8 * g;
+      bs[j][g] = (p.bias && col < Cout) ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
+    }
+  float4 r1[2][4], r2[2][4];
+  auto group = [&](int ij, size_t& obase, int& cb) {  // -> pixel in range
+    const int i = ij / TN, j = ij - i * TN;
     const int r = (wm * TM + i) * 32 + (lane & 31);
-    const int y = y0 + (r >> 4), x = x0 + (r & 15);
-    if (y >= H || x >= W) continue;
-    const size_t obase = (((size_t)n * H + y) * W + x) * Cout;
+    const int y = y0 + (r >> LGX), x = x0 + (r & (TPX - 1));
+    obase = (((size_t)n * H + y) * W + x) * Cout;
+    cb = n0 + (wn * TN + j) * 32 + h4;
+    return y < H && x < W;
+  };
+  auto res_load = [&](int ij, float4 (&a)[4], float4 (&b)[4]) {
+    size_t obase; int cb;
+    const bool in = group(ij, obase, cb);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int cb = n0 + (wn * TN + j) * 32 + h4;
+    for (int g = 0; g < 4; ++g) {
+      const int col = cb + 8 * g;
+      const bool ok = in && col < Cout;
+      a[g] = (p.resid && ok) ? *(const float4*)(p.resid + obase + col) : make_float4(0, 0, 0, 0);
+      b[g] = (p.resid2 && ok) ? *(const float4*)(p.resid2 + obase + col) : make_float4(0, 0, 0, 0);
+    }
+  };
+  res_load(0, r1[0], r2[0]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = cb + 8 * g;
-        if (col >= Cout) continue;
-        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        if (p.bias) {
-          const float4 bs = *(const float4*)(p.bias + col);
-          v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
-        }
-        if (p.resid) {
-          float4 rr = *(const float4*)(p.resid + obase + col);
-          if (p.resid_relu) rr = make_float4(fmaxf(rr.x, 0.f), fmaxf(rr.y, 0.f), fmaxf(rr.z, 0.f), fmaxf(rr.w, 0.f));
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        if (p.resid2) {
-          const float4 rr = *(const float4*)(p.resid2 + obase + col);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        if (p.relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        *(float4*)(p.y + obase + col) = v;
-      }
+  for (int ij = 0; ij < TM * TN; ++ij) {
+    if (ij + 1 < TM * TN) res_load(ij + 1, r1[(ij + 1) & 1], r2[(ij + 1) & 1]);
+    const int i = ij / TN, j = ij - i * TN;
+    size_t obase; int cb;
+    const bool in = group(ij, obase, cb);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = cb + 8 * g;
+      float4 v = make_float4(acc[i][j][4 * g] + bs[j][g].x, acc[i][j][4 * g + 1] + bs[j][g].y, acc[i][j][4 * g + 2] + bs[j][g].z, acc[i][j][4 * g + 3] + bs[j][g].w);
+      float4 rr = r1[ij & 1][g];
+      if (p.resid_relu) rr = make_float4(fmaxf(rr.x, 0.f), fmaxf(rr.y, 0.f), fmaxf(rr.z, 0.f), fmaxf(rr.w, 0.f));
+      const float4 r2v = r2[ij & 1][g];
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      v.x += r2v.x; v.y += r2v.y; v.z += r2v.z; v.w += r2v.w;
+      if (p.relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (in && col < Cout) *(float4*)(p.y + obase + col) = v;
     }
   }
 }
 
-template <int T, int WM, int WN, int TM, int TN, int UP = 0>
+template <int T, int WM, int WN, int TM, int TN, int UP = 0, int TPX = 16>
 hipError_t launch_rs(const WmConvArgs& a, hipStream_t s) {
-  constexpr int BN = WN * TN * 32;
-  const size_t shm = 2 * HALO_BYTES + 2 * BN * 128;
+  constexpr int BN = WN * TN * 32, TPY = 256 / TPX;
+  const size_t shm = 2 * (size_t)(TPX + 2) * (TPY + 2) * 128 + 2 * BN * 128;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_rs_kernel<T, WM, WN, TM, TN, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)conv3x3_rs_kernel<T, WM, WN, TM, TN, UP, TPX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
-  const int nblk = a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP) * ((a.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL((conv3x3_rs_kernel<T, WM, WN, TM, TN, UP>), dim3(nblk), dim3(512), shm, s, a);
+  const int nblk = a.N * ((a.Hi + TPY - 1) / TPY) * ((a.Wi + TPX - 1) / TPX) * ((a.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL((conv3x3_rs_kernel<T, WM, WN, TM, TN, UP, TPX>), dim3(nblk), dim3(512), shm, s, a);
   return hipGetLastError();
 }
 
@@ -636,6 +660,14 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   const bool rs_ok = (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0;
   const bool rs = rs_ok && a.up_hs == 0;  // register-staged main loop (plain input, even chunk count)
   if (rs_ok && a.up_hs > 0 && bn == 128) return launch_rs<T, 4, 2, 2, 2, 1>(a, s);  // fused resize, 128-channel tile
+  if (rs && bn >= 128 && wm_tuning[WM_TUNE_CONV_TPX] != 16) {
+    // pixel-tile shape: rounds over the CUs (one block per CU) with 16 x 16 vs 32 x 8 tiles
+    const long ct = (a.Cout + bn - 1) / bn;
+    const long t16 = ptiles * ct, t32 = (long)a.N * ((a.Hi + 7) / 8) * ((a.Wi + 31) / 32) * ct;
+    const long r16 = (t16 + ncu - 1) / ncu, r32 = (t32 + ncu - 1) / ncu;
+    if (r32 < r16 || (r32 == r16 && t32 < t16) || wm_tuning[WM_TUNE_CONV_TPX] == 32)  // fewer rounds, else fewer (less ragged) tiles
+      return bn >= 256 ? launch_rs<T, 2, 4, 4, 2, 0, 32>(a, s) : launch_rs<T, 4, 2, 2, 2, 0, 32>(a, s);
+  }
   if (bn >= 256) return rs ? launch_rs<T, 2, 4, 4, 2>(a, s) : launch_cfg<T, 2, 4, 4, 2>(a, s);   // 256 px x 256 ch (a two-group ping-pong main loop was tried here: bit-identical, no faster)
   if (bn >= 128) return rs ? launch_rs<T, 4, 2, 2, 2>(a, s) : launch_cfg<T, 4, 2, 2, 2>(a, s);   // 256 px x 128 ch
   if (bn >= 64) return launch_cfg<T, 4, 2, 2, 1>(a, s);    // 256 px x 64 ch (register staging measured equal here)

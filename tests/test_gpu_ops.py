@@ -368,6 +368,35 @@ def test_conv(dev, Cin, Cout, ks, stride, Hh, Ww):
         assert e < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,Hh,Ww", [(256, 256, 37, 37), (256, 256, 70, 45), (256, 128, 40, 40), (128, 128, 33, 100), (256, 256, 148, 148)])
+def test_conv3x3_wide_pixel_tile(dev, Cin, Cout, Hh, Ww):
+    """conv3x3_rs_kernel with 32 x 8 pixel tiles (chosen automatically where it saves a round over the CUs, e.g. 148^2
+    at 8 views; forced here with conv_tpx = 32) against the fp32 torch reference and against the 16 x 16 tiling."""
+    dt = F16
+    g = torch.Generator().manual_seed(Cin + Cout + Hh)
+    N = 2
+    x = torch.randn(N, Hh, Ww, Cin, generator=g).to(dev)
+    w = _t16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9), dt).float().to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    resid = torch.randn(N, Hh, Ww, Cout, generator=g).to(dev)
+    resid2 = torch.randn(N, Hh, Ww, Cout, generator=g).to(dev)
+    w16 = _t16(w.permute(0, 2, 3, 1).contiguous(), dt)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = _conv_ref(x, w, b, 1, 1, 1, resid, True, resid2, dt)
+    outs = {}
+    try:
+        for tpx in (32, 16):
+            assert _lib().wm_set_tuning(b"conv_tpx", tpx) == 0
+            y = torch.full((N, Hh, Ww, Cout), float("nan"), device=dev)
+            assert _lib().wm_op_conv(dt, _p(x), _p(w16), _p(b), _p(resid), _p(resid2), _p(y), N, Hh, Ww, Cin, Cout, 3, 1, 1, 1, 1, s) == 0
+            torch.cuda.synchronize()
+            assert _rel(y, ref) < 2e-5, (tpx, _rel(y, ref))
+            outs[tpx] = y
+    finally:
+        _lib().wm_set_tuning(b"conv_tpx", -1)
+    assert torch.equal(outs[16], outs[32])  # same accumulation order per output element
+
+
 @pytest.mark.parametrize("Cin,Cout,Hs,Ws,Hi,Wi,pos", [(256, 128, 20, 16, 40, 32, False), (128, 32, 40, 32, 70, 56, True),
                                                     (64, 64, 9, 11, 33, 40, True), (256, 128, 148, 148, 296, 296, False)])
 def test_conv3x3_fused_upsample(dev, Cin, Cout, Hs, Ws, Hi, Wi, pos):
