@@ -73,10 +73,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
   const int nseq = p.q_rows / p.seq_len;
   const int tiles_per_head = tiles_per_seq * nseq;
-  const int nsplit = p.kv_splits;
-  int lid = xcd_remap(blockIdx.x, tiles_per_head * p.H * nsplit);
-  const int split = lid % nsplit;
-  lid /= nsplit;
+  // Units (q-tile, head) [0, full_units) are processed whole by the first full_units blocks; every later unit is walked by
+  // kv_splits blocks, each over a slice of the key tiles (partials + combine pass).  full_units = 0 is the uniform split;
+  // the launcher uses full_units > 0 to cut only the LAST, partly filled round of a launch into short blocks.
+  const int nfull = p.kv_splits > 1 ? p.full_units : tiles_per_head * p.H;
+  const bool whole = (int)blockIdx.x < nfull;  // block-uniform
+  const int nsplit = whole ? 1 : p.kv_splits;
+  int lid, split = 0;
+  if (whole) {
+    lid = xcd_remap(blockIdx.x, nfull);
+  } else {
+    lid = xcd_remap(blockIdx.x - nfull, (tiles_per_head * p.H - nfull) * nsplit);
+    split = lid % nsplit;
+    lid = nfull + lid / nsplit;
+  }
   const int head = lid / tiles_per_head;
   const int tile = lid - head * tiles_per_head;
   const int seq = tile / tiles_per_seq;
@@ -631,15 +641,20 @@ hipError_t launch_sp(const WmAttnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// O[row][head*64 + d] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s ; one thread per (row, head, 4 channels)
+// O[row][head*64 + d] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s for the split units [full_units, units); a block
+// of 256 threads = 16 query rows of one unit x 16 groups of 4 channels (QT = query rows per unit)
 template <int T>
-__global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p) {
-  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int d4 = (int)(id & 15);
-  const size_t rh = id >> 4;
-  const int head = (int)(rh % p.H);
-  const size_t row = rh / p.H;
-  if (row >= (size_t)p.q_rows) return;
+__global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p, int QT) {
+  const int bpu = QT / 16;  // blocks per unit
+  const int unit = p.full_units + (int)(blockIdx.x / bpu);
+  const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
+  const int tiles_per_head = tiles_per_seq * (p.q_rows / p.seq_len);
+  const int head = unit / tiles_per_head, tile = unit - head * tiles_per_head;
+  const int seq = tile / tiles_per_seq, qt = tile - seq * tiles_per_seq;
+  const int r = qt * QT + (int)(blockIdx.x % bpu) * 16 + (threadIdx.x >> 4);
+  if (r >= p.seq_len) return;
+  const size_t row = (size_t)seq * p.seq_len + r;
+  const int d4 = threadIdx.x & 15;
   float m[WM_ATTN_MAX_SPLITS], l[WM_ATTN_MAX_SPLITS], M = -INFINITY;
   for (int s = 0; s < p.kv_splits; ++s) {
     const float2 ml = *(const float2*)(p.part_ml + (((size_t)s * p.H + head) * p.q_rows + row) * 2);
@@ -683,15 +698,33 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
     // 2 (tools/bench_attn_split_chunks.py).  On one GPU (kv_chunks == 1) the combine pass costs what the better
     // balance gains (8 views: 940 vs 940 TF/s) and the short per-frame sequences lose 20 %.
     else if (a.kv_chunks > 1 && lim >= 2) best = lim < 4 ? lim : 4;
-    (void)blocks; (void)slots;
     a.kv_splits = best;
+    a.full_units = 0;
+    // Tail split (one GPU): the launch's last, partly filled round — e.g. 688 units on 512 slots at 8 views: 176 whole
+    // blocks, one per CU, with 80 CUs idle — is cut into S short blocks per unit, so that it fills the chip again.
+    // Model, in units of a full round: a partial round whose blocks sit alone on their CU runs 1.37x faster (measured:
+    // one wave per SIMD is 1.46x slower per wave); a slice costs 1 / S; the combine pass ~0.01 per slice.  Measured
+    // (tools/bench_attn_tail.py): 8 views 530 -> 480-495 us (+8-10 %), 16 views +8 %, 32 views +4-7 %; the short
+    // per-frame sequences (22 key tiles) lose 10 % and are left alone (ntiles >= 64).
+    const long tail = blocks % slots;
+    if (a_in.kv_splits == 0 && best == 1 && lim >= 2 && a.kv_chunks == 1 && ntiles >= 64 && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
+      auto round_cost = [&](long n) { const long rem = n % slots; return (double)(n / slots) + (rem == 0 ? 0.0 : rem * 2 <= slots ? 0.73 : 1.0); };
+      double best_cost = round_cost(tail);
+      int bs = 1;
+      for (int S = 2; S <= lim; ++S) {
+        const double c = round_cost(tail * S) / S + 0.01 * S;
+        if (c < best_cost - 0.05) { best_cost = c; bs = S; }
+      }
+      if (wm_tuning[WM_TUNE_ATTN_TAIL] > 1) bs = wm_tuning[WM_TUNE_ATTN_TAIL] < lim ? wm_tuning[WM_TUNE_ATTN_TAIL] : lim;  // A/B: forced slice count
+      if (bs > 1) { a.kv_splits = bs; a.full_units = (int)(blocks - tail); }
+    }
   }
-  dim3 grid(tiles_per_seq * nseq * a.H * a.kv_splits), block(NW * 64);
+  const int units = tiles_per_seq * nseq * a.H;
+  const int nfull = a.kv_splits > 1 ? a.full_units : units;
+  dim3 grid(nfull + (units - nfull) * a.kv_splits), block(NW * 64);
   hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, LZ, STG>), grid, block, 0, s, a);
-  if (a.kv_splits > 1) {
-    const size_t nthr = (size_t)a.q_rows * a.H * 16;
-    hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
-  }
+  if (a.kv_splits > 1)
+    hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((units - nfull) * (QT / 16))), dim3(256), 0, s, a, QT);
   return hipGetLastError();
 }
 

@@ -54,10 +54,11 @@ struct WmAttnArgs {
   // the key tiles and writes an unnormalised partial; wm_launch_attention runs the combine pass itself.
   // kv_splits 0 = choose (1 when no workspace is given); part_o: fp32 [kv_splits][q_rows][H*64]; part_ml: fp32 [kv_splits][H][q_rows][2]
   int kv_splits, max_splits;
+  int full_units;      // set by the launcher: units (q-tile, head) processed whole; the rest is split kv_splits ways (0 = all split)
   float* part_o; float* part_ml;
 };
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s);
-constexpr int WM_ATTN_MAX_SPLITS = 4;
+constexpr int WM_ATTN_MAX_SPLITS = 8;
 
 // ------------------------------------------------------------------ elementwise (elementwise.hip)
 // LayerNorm over the last dim with row remapping: out row (g*out_group + out_off + q) <- in row
@@ -142,6 +143,6 @@ hipError_t wm_launch_cam_matrices(const float* params, float* poses, float* intr
 
 // Process-wide tuning overrides (wm_set_tuning in the C ABI; tests and A/B tools).  -1 = not set: the kernel's
 // launcher falls back to its environment variable, then to its built-in choice.
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

@@ -269,8 +269,8 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("H16", Mx * 4 * D * 2);
   for (int i = 0; i < 4; ++i) add(("tap" + std::to_string(i)).c_str(), Mv * 2 * D * 4);
   add("KVG", (size_t)d.world * 2 * Mv * D * 2);
-  add("ATT_PO", (size_t)(d.world > 1 ? 4 : 1) * Mx * D * 4);   // split-KV attention partials (sharded path: 4 slices): unnormalised O, (max, sum)
-  add("ATT_ML", (size_t)(d.world > 1 ? 4 : 1) * Mx * (D / 64) * 2 * 4);
+  add("ATT_PO", (size_t)(d.world > 1 ? 4 : WM_ATTN_MAX_SPLITS) * Mx * D * 4);   // split-KV attention partials (sharded path: 4 slices; one GPU: the tail round, up to 8): unnormalised O, (max, sum)
+  add("ATT_ML", (size_t)(d.world > 1 ? 4 : WM_ATTN_MAX_SPLITS) * Mx * (D / 64) * 2 * 4);
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("dino_pos", (size_t)(1 + d.hw) * D * 4);
@@ -419,7 +419,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -753,7 +753,7 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     } else {
       a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
     }
-    a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = d.world > 1 ? 4 : 1;
+    a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = d.world > 1 ? 4 : WM_ATTN_MAX_SPLITS;
     ProfScope ps(h, is_global ? 0 : 1, c.s);
     LCHK(c, wm_launch_attention(a, c.s));
   }

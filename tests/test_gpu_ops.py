@@ -238,6 +238,40 @@ def test_attention_split_kv(dev, H, L, chunks, splits):
     assert _rel(a2, a1) < 6e-3  # both round P and O to bf16, in different groupings
 
 
+@pytest.mark.parametrize("H,nseq,L", [(16, 1, 11008), (16, 2, 4200), (40, 1, 4100), (33, 2, 5000)])
+def test_attention_tail_split(dev, H, nseq, L):
+    """Automatic tail split (one GPU, workspace given, kv_splits = 0): only the units of the launch's last, partly filled
+    round are cut into key slices + combine pass; every other unit is written by its single block.  Checked against the
+    unsplit kernel on the same inputs (every row, so whole and split units alike) and against fp32 softmax."""
+    g = torch.Generator().manual_seed(H + nseq + L)
+    R = nseq * L
+    q = torch.randn(H, R, 64, generator=g) * 0.125 * LOG2E
+    k = torch.randn(H, R, 64, generator=g)
+    v = torch.randn(H, R, 64, generator=g)
+    k[:, L - 3] = q[:, 40] * 8 * 30.0  # a spike key in the last slice of sequence 0
+    q, k, v = [_t16(x, BF16).to(dev) for x in (q, k, v)]
+    o1 = torch.zeros(R, H * 64, device=dev, dtype=torch.int16)
+    o2 = torch.zeros(R, H * 64, device=dev, dtype=torch.int16)
+    po = torch.zeros((8, R, H * 64), device=dev)
+    pml = torch.zeros((8, H, R, 2), device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L_ = _lib()
+    assert L_.wm_op_attention(BF16, _p(q), _p(k), _p(v), _p(o1), H, R, L, 1, 0, s) == 0
+    assert L_.wm_op_attention_split(BF16, _p(q), _p(k), _p(v), _p(o2), H, R, L, 1, 0, 0, _p(po), _p(pml), s) == 0
+    torch.cuda.synchronize()
+    units = H * nseq * ((L + 255) // 256)
+    assert units > 512, "the case must span more than one round of 512 resident blocks"
+    assert bool((po != 0).any()), "the tail units must have gone through the partial buffers"
+    a1, a2 = _from16(o1, BF16).reshape(R, H, 64), _from16(o2, BF16).reshape(R, H, 64)
+    same = (o1 == o2).reshape(R, H, 64).all(-1)  # [row][head]: whole units are bit-identical to the unsplit launch
+    print(f"tail split H{H} nseq{nseq} L{L}: identical (row, head) pairs {float(same.float().mean()):.3f}, tail-vs-single {_rel(a2, a1):.2e}")
+    assert 0.3 < float(same.float().mean()) < 1.0
+    assert _rel(a2, a1) < 6e-3
+    for hh in (0, H - 1):  # fp32 reference on the first (whole) and last (split) head, sequence 0
+        ref = _attn_ref(q[hh:hh + 1, :L].float(), k[hh:hh + 1, :L].float(), v[hh:hh + 1, :L].float())[0]
+        assert _rel(a2[:L, hh], ref) < 8e-3
+
+
 @pytest.mark.parametrize("D", [128, 256, 1024, 2048])
 def test_layernorm(dev, D):
     g = torch.Generator().manual_seed(D)
