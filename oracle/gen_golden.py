@@ -121,7 +121,7 @@ def make_inputs(seed: int, S: int, H: int, W: int, priors: bool):
     return views
 
 
-def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="sensitive"):
+def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="sensitive", splat_stride=1):
     views_np = make_inputs(seed, S, H, W, priors=sum(flags) > 0)
     views = {k: torch.from_numpy(v.copy()) for k, v in views_np.items()}
     store = {f"in_{k}": v for k, v in views_np.items()}
@@ -144,12 +144,16 @@ def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="
             from einops import rearrange
             gp = m.gs_renderer.gs_head(rearrange(f, "b s c h w -> (b s) c h w"))
             sp = m.gs_renderer.prepare_splats(views, preds, views["img"], gp, S, 0)
-            store["gs_feat"] = f.numpy()
+            if splat_stride == 1:
+                store["gs_feat"] = f.numpy()
             for k in ("means", "quats", "scales", "opacities", "sh", "weights"):
-                store[f"splats_raw_{k}"] = sp[k][0].numpy()
-            pr = m.gs_renderer.prune_gs(sp)
-            for k in ("means", "quats", "scales", "opacities", "sh"):
-                store[f"splats_{k}"] = pr[k][0].numpy()
+                store[f"splats_raw_{k}"] = np.ascontiguousarray(sp[k][0].numpy()[::splat_stride])  # per-pixel splats, every splat_stride-th
+                store[f"sum_splats_raw_{k}"] = np.array(sp[k][0].double().sum().item())
+            store["splat_stride"] = np.array(splat_stride)
+            if splat_stride == 1:  # the voxel-merged set is only kept for the small fixtures (it is as large as the per-pixel one)
+                pr = m.gs_renderer.prune_gs(sp)
+                for k in ("means", "quats", "scales", "opacities", "sh"):
+                    store[f"splats_{k}"] = pr[k][0].numpy()
             preds_np = {k: v.numpy() for k, v in preds.items()}
         else:
             preds = m._gen_all_preds(taps, views["img"], psi, views)
@@ -177,12 +181,18 @@ def main():
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--refinit", action="store_true", help="goldens with the reference's own init statistics")
     ap.add_argument("--full-priors", action="store_true", help="full architecture, 2 x 224^2, pose + intrinsics priors (the C3 flag set)")
+    ap.add_argument("--full-gs", action="store_true", help="full architecture with the 3D-Gaussian head (BASELINE config 5 path, rasterisation not run), 2 x 224^2")
     a = ap.parse_args()
     torch.manual_seed(0)
     if a.full_priors:
         cfg = WMConfig()
         m = build_reference(cfg)
         run_case(m, cfg, "full_2v_224_pose_ray", 12, 2, 224, 224, [1, 0, 1], sub=4, keep_taps=False)
+        return
+    if a.full_gs:
+        cfg = WMConfig(enable_gs=True)
+        m = build_reference(cfg)
+        run_case(m, cfg, "full_gs_2v_224", 13, 2, 224, 224, [0, 0, 0], sub=4, keep_taps=False, splat_stride=16)
         return
     if a.refinit:
         cfg = WMConfig.tiny()

@@ -156,6 +156,36 @@ def test_tiny_gs_branch_golden():
         assert e < 1e-2, (k, e)
 
 
+def test_full_arch_gs_branch_golden():
+    """BASELINE config 5's path at the full 1.26 B-parameter architecture (3D-Gaussian head on, rasterisation stubbed as the
+    reference's result is discarded, rasterization.py:243-246), 2 x 224^2, against the reference's outputs."""
+    cfg, views, flags, outs, z = load_golden("full_gs_2v_224")
+    m = _model(cfg)
+    got = _run(m, views, flags)
+    sub, st = int(z["subsample"]), int(z["splat_stride"])
+    errs = {}
+    for k in ("gs_depth", "gs_depth_conf", "camera_params"):
+        g = got[k].cpu().numpy()
+        if g.ndim >= 4 and g.shape[2] == 224:
+            g = g[:, :, ::sub, ::sub]
+        assert g.shape == outs[k].shape, k
+        errs[k] = rel_l2(g, outs[k])
+    for k in ("means", "quats", "scales", "opacities", "sh", "weights"):
+        raw = got["splats_raw"][k][0]
+        errs["raw_" + k] = rel_l2(raw.cpu().numpy()[::st], z["splats_raw_" + k])
+        ref = float(z["sum_splats_raw_" + k])  # fp64 checksum over ALL per-pixel splats (not only the stored 16th)
+        errs["sum_" + k] = abs(float(raw.double().sum()) - ref) / max(abs(ref), 1.0)
+    print("full gs", {k: f"{e:.2e}" for k, e in errs.items()})
+    # means = unprojection of gs_depth through the PREDICTED camera (rasterization.py:469-484): they inherit the camera
+    # head's error (focal / translation), the other attributes come straight from the head
+    for k in ("quats", "scales", "opacities", "sh", "weights"):
+        assert errs["sum_" + k] < 5e-3, (k, errs["sum_" + k])
+    assert errs["sum_means"] < 2e-2
+    assert errs["gs_depth"] < 2e-3 and errs["gs_depth_conf"] < 1e-3 and errs["camera_params"] < 5e-3
+    for k, e in errs.items():
+        assert e < (2e-2 if "means" in k else 1e-2), (k, e)
+
+
 def test_errors_mirror_reference():
     from hunyuanworld_mirror_amd import WorldMirror, WMConfig
     cfg = WMConfig.tiny()

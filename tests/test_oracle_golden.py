@@ -64,6 +64,26 @@ def test_oracle_gs_branch_matches_reference():
         assert rel_l2(o["splats"][k].numpy(), z["splats_" + k]) < TOL, k
 
 
+@pytest.mark.skipif(os.environ.get("WM_SKIP_FULL_ORACLE") == "1", reason="skipped by env")
+def test_oracle_gs_branch_matches_reference_full():
+    """BASELINE config 5's path at the full architecture (2 x 224^2, 3D-Gaussian head on, rasterisation not run):
+    gs_depth / confidence (every 4th pixel), the per-pixel splats of prepare_splats (every 16th) and fp64 checksums
+    of all of them."""
+    cfg, o, outs, z, col = _run("full_gs_2v_224")
+    sub, st = int(z["subsample"]), int(z["splat_stride"])
+    for k, v in outs.items():
+        got = o[k].numpy()
+        if got.ndim >= 4 and got.shape[2] == 224:
+            got = got[:, :, ::sub, ::sub]
+        assert got.shape == v.shape, k
+        assert rel_l2(got, v) < 2e-5, k
+    for k in ("means", "quats", "scales", "opacities", "sh", "weights"):
+        raw = col["splats_raw"][k]
+        assert rel_l2(raw.numpy()[::st], z["splats_raw_" + k]) < 2e-5, k
+        ref = float(z["sum_splats_raw_" + k])
+        assert abs(float(raw.double().sum()) - ref) <= 1e-5 * max(abs(ref), 1.0), k
+
+
 def test_prune_gs_merges_voxels():
     # property: with a coarse voxel everything in one cell collapses to the weighted mean
     sp = {"means": torch.tensor([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [5.0, 5.0, 5.0]]),
