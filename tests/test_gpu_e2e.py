@@ -156,11 +156,12 @@ def test_tiny_gs_branch_golden():
         assert e < 1e-2, (k, e)
 
 
-def test_full_arch_gs_branch_golden():
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_full_arch_gs_branch_golden(dtype):
     """BASELINE config 5's path at the full 1.26 B-parameter architecture (3D-Gaussian head on, rasterisation stubbed as the
     reference's result is discarded, rasterization.py:243-246), 2 x 224^2, against the reference's outputs."""
     cfg, views, flags, outs, z = load_golden("full_gs_2v_224")
-    m = _model(cfg)
+    m = _model(cfg, dtype=dtype)  # config 5 quotes fp16; bf16 is the default recipe
     got = _run(m, views, flags)
     sub, st = int(z["subsample"]), int(z["splat_stride"])
     errs = {}
@@ -175,7 +176,7 @@ def test_full_arch_gs_branch_golden():
         errs["raw_" + k] = rel_l2(raw.cpu().numpy()[::st], z["splats_raw_" + k])
         ref = float(z["sum_splats_raw_" + k])  # fp64 checksum over ALL per-pixel splats (not only the stored 16th)
         errs["sum_" + k] = abs(float(raw.double().sum()) - ref) / max(abs(ref), 1.0)
-    print("full gs", {k: f"{e:.2e}" for k, e in errs.items()})
+    print("full gs", dtype, {k: f"{e:.2e}" for k, e in errs.items()})
     # means = unprojection of gs_depth through the PREDICTED camera (rasterization.py:469-484): they inherit the camera
     # head's error (focal / translation), the other attributes come straight from the head
     for k in ("quats", "scales", "opacities", "sh", "weights"):

@@ -61,3 +61,44 @@ def test_c2_view_permutation_equivariance(model_and_out):
         assert e < 4e-3, k
     # and it is a real swap, not an identity: the un-permuted comparison must be far off
     assert rel_l2(got["depth"].cpu().numpy(), out["depth"].cpu().numpy()) > 1e-2
+
+
+def _c3_inputs(n=32):
+    """BASELINE config C3 inputs as bench.py --priors builds them: identity rotations, x = 0.1 i, fx = fy = 518."""
+    g = torch.Generator().manual_seed(4321)
+    img = torch.rand(1, n, 3, 518, 518, generator=g)
+    pose = torch.eye(4).repeat(1, n, 1, 1)
+    pose[0, :, 0, 3] = 0.1 * torch.arange(n)
+    K = torch.zeros(1, n, 3, 3)
+    K[..., 0, 0] = 518; K[..., 1, 1] = 518; K[..., 0, 2] = 259; K[..., 1, 2] = 259; K[..., 2, 2] = 1
+    return {"img": img.cuda(), "camera_pose": pose.cuda(), "camera_intrinsics": K.cuda()}
+
+
+def test_c3_32_views_with_priors(model_and_out):
+    """BASELINE config C3 (32 views x 518^2, camera-pose + intrinsics priors on) at full size: output invariants, bit-exact
+    determinism (the cross-view attention runs its tail-split + combine path here: 2752 units on 512 slots), the priors
+    are really consumed (flags off changes the result), and views 1..31 stay exchangeable when their priors move with them."""
+    m, _, _ = model_and_out
+    views = _c3_inputs(32)
+    out = {k: v.clone() for k, v in m(views, [1, 0, 1]).items()}
+    torch.cuda.synchronize()
+    assert out["pts3d"].shape == (1, 32, 518, 518, 3) and out["camera_params"].shape == (1, 32, 9)
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    assert (out["depth"] > 0).all() and (out["pts3d_conf"] >= 1).all()
+    assert float((out["normals"].norm(dim=-1) - 1).abs().max()) < 1e-4
+    again = m(views, [1, 0, 1])
+    torch.cuda.synchronize()
+    for k in ("pts3d", "depth", "normals", "camera_params"):
+        assert torch.equal(again[k], out[k]), k
+    off = m(views, [0, 0, 0])
+    torch.cuda.synchronize()
+    assert rel_l2(off["camera_params"].cpu().numpy(), out["camera_params"].cpu().numpy()) > 1e-4  # pose / ray tokens were zeros
+    perm = list(range(32)); perm[3], perm[17] = perm[17], perm[3]
+    pv = {k: v[:, perm].contiguous() for k, v in views.items()}
+    got = m(pv, [1, 0, 1])
+    torch.cuda.synchronize()
+    for k in ("pts3d", "depth", "camera_params"):
+        e = rel_l2(got[k].cpu().numpy(), out[k][:, perm].cpu().numpy())
+        print("c3 perm", k, f"{e:.2e}")
+        assert e < 4e-3, k
