@@ -143,6 +143,20 @@ hipError_t wm_launch_cam_matrices(const float* params, float* poses, float* intr
 
 // Process-wide tuning overrides (wm_set_tuning in the C ABI; tests and A/B tools).  -1 = not set: the kernel's
 // launcher falls back to its environment variable, then to its built-in choice.
+// ------------------------------------------------------------------ 3D-Gaussian rasteriser (raster.hip)
+struct WmRasterArgs {
+  const float* means; const float* quats; const float* scales; const float* opacities;  // [N,3] [N,4 wxyz] [N,3] [N]
+  const float* colors; int is_sh;       // [N,3]: degree-0 SH coefficients (is_sh = 1) or final colours
+  int N;
+  const float* viewmats; const float* Ks; int C;  // world-to-camera [C,4,4], intrinsics [C,3,3]
+  int width, height;
+  float* out_rgb; float* out_depth; float* out_alpha;  // [C,H,W,3] [C,H,W] [C,H,W]
+  int* radii_out;                       // optional [C,N,2] (tests)
+  void* workspace; size_t workspace_bytes; size_t max_isects;
+};
+size_t wm_raster_workspace_bytes(int N, int C, int width, int height, size_t max_isects);
+hipError_t wm_launch_rasterize(const WmRasterArgs& a, hipStream_t s, unsigned long long* n_isects_out);
+
 enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

@@ -1251,6 +1251,29 @@ extern "C" wm_status wm_op_attention_split(int dtype, const void* Q, const void*
   }
   return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
+extern "C" size_t wm_rasterize_workspace_bytes(int n_gaussians, int n_cameras, int width, int height, size_t max_isects) {
+  return wm_raster_workspace_bytes(n_gaussians, n_cameras, width, height, max_isects);
+}
+extern "C" wm_status wm_rasterize_splats(const float* means, const float* quats, const float* scales, const float* opacities,
+                                         const float* colors, int colors_are_sh0, int n_gaussians, const float* viewmats, const float* Ks,
+                                         int n_cameras, int width, int height, float* out_rgb, float* out_depth, float* out_alpha,
+                                         int* radii_out, void* workspace, size_t workspace_bytes, size_t max_isects,
+                                         unsigned long long* n_isects, void* stream) {
+  if (!means || !quats || !scales || !opacities || !colors || !viewmats || !Ks || !out_rgb || !out_depth || !out_alpha || !workspace)
+    return WM_ERR_INVALID;
+  WmRasterArgs a;
+  memset(&a, 0, sizeof(a));
+  a.means = means; a.quats = quats; a.scales = scales; a.opacities = opacities; a.colors = colors; a.is_sh = colors_are_sh0;
+  a.N = n_gaussians; a.viewmats = viewmats; a.Ks = Ks; a.C = n_cameras; a.width = width; a.height = height;
+  a.out_rgb = out_rgb; a.out_depth = out_depth; a.out_alpha = out_alpha; a.radii_out = radii_out;
+  a.workspace = workspace; a.workspace_bytes = workspace_bytes; a.max_isects = max_isects;
+  unsigned long long n = 0;
+  const hipError_t e = wm_launch_rasterize(a, (hipStream_t)stream, &n);
+  if (n_isects) *n_isects = n;
+  if (e == hipErrorInvalidValue) return WM_ERR_INVALID;
+  if (e != hipSuccess) return WM_ERR_HIP;
+  return n > max_isects ? WM_ERR_STATE : WM_OK;  // WM_ERR_STATE: the workspace is too small for *n_isects pairs, nothing was rendered
+}
 extern "C" wm_status wm_op_layernorm(const float* x, void* y, const float* w, const float* b, int rows, int D, float eps, int out_f32,
                                      int dtype, void* stream) {
   WmLnArgs a;

@@ -117,11 +117,15 @@ def prune_gs(splats: Dict[str, torch.Tensor], voxel_size: float = 0.002) -> Dict
     return out
 
 
-class _GSRendererStub:
-    """Placeholder for ``model.gs_renderer`` (infer.py:264): rasterisation is out of scope."""
+class _GSRenderer:
+    """``model.gs_renderer`` as the callers use it (infer.py:264 -> render_interpolated_video, src/utils/render_utils.py:121):
+    the object carrying ``.rasterizer`` (rasterization.py:133).  The splat head itself runs inside ``wm_forward``; the
+    forward pass does not rasterise (the reference discards that result, rasterization.py:243-246)."""
 
-    def __getattr__(self, name):
-        raise NotImplementedError("gsplat rasterisation is stubbed in the MI355X build (BASELINE config 5)")
+    def __init__(self):
+        from .rasterization import Rasterizer
+        self.rasterizer = Rasterizer()
+        self.enable_prune, self.voxel_size, self.sh_degree = True, 0.002, 0
 
 
 class WorldMirror:
@@ -147,7 +151,7 @@ class WorldMirror:
         self.dtype, self.head_dtype = dtype, head_dtype
         self.enable_cam, self.enable_pts = arch.enable_cam, arch.enable_pts
         self.enable_depth, self.enable_norm, self.enable_gs = arch.enable_depth, arch.enable_norm, arch.enable_gs
-        self.gs_renderer = _GSRendererStub()
+        self.gs_renderer = _GSRenderer()
         self._host_weights: Dict[str, np.ndarray] = {}
         self._handle = None
         self._device: Optional[torch.device] = None

@@ -164,6 +164,25 @@ size_t wm_confidence_mask_workspace_bytes(size_t n);
 wm_status wm_confidence_mask(const float* conf, size_t n, float conf_threshold_percent, unsigned char* mask, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* 3D-Gaussian-splat rasteriser forward — replaces gsplat.rasterization as the reference calls it through
+ * Rasterizer.rasterize_splats (src/models/models/rasterization.py:29-66; callers: GaussianSplatRenderer.render :221-241,
+ * render_interpolated_video src/utils/render_utils.py:242-312 <- infer.py:264): packed, rasterize_mode "classic", pinhole,
+ * render_mode "RGB+ED" (colour + expected depth), tile size 16, eps2d 0.3, near plane 0.01, no background.
+ * means [N,3], quats [N,4] (wxyz, normalised inside), scales [N,3], opacities [N], colors [N,3]: degree-0 SH coefficients
+ * (colors_are_sh0 = 1: colour = max(0.2820948 sh + 0.5, 0), the reference's sh_degree = 0 call) or final colours (0: the
+ * reference's sh_degree = None call); viewmats [C,4,4] WORLD-TO-CAMERA (the reference inverts its camtoworlds before the
+ * call, :48), Ks [C,3,3].  Outputs (caller-owned device buffers): out_rgb [C,H,W,3], out_depth [C,H,W] (expected depth
+ * = sum w z / sum w), out_alpha [C,H,W]; radii_out optional [C,N,2] int32 (the projection's screen radii, 0 = culled).
+ * The number of (Gaussian, tile) pairs is data dependent: the call synchronises the stream once to read it (as the
+ * reference's isect_tiles does); if it exceeds max_isects the call returns WM_ERR_STATE with *n_isects = the required count
+ * and renders nothing — re-size the workspace with wm_rasterize_workspace_bytes and call again. */
+size_t wm_rasterize_workspace_bytes(int n_gaussians, int n_cameras, int width, int height, size_t max_isects);
+wm_status wm_rasterize_splats(const float* means, const float* quats, const float* scales, const float* opacities,
+                              const float* colors, int colors_are_sh0, int n_gaussians, const float* viewmats, const float* Ks,
+                              int n_cameras, int width, int height, float* out_rgb, float* out_depth, float* out_alpha,
+                              int* radii_out, void* workspace, size_t workspace_bytes, size_t max_isects,
+                              unsigned long long* n_isects, void* stream);
+
 /* Process-wide kernel-selection override for tests and A/B tools (no reference counterpart).  key: "gemm_cfg"
  * (tile config id), "gemm_pp" (0/1 ping-pong GEMM), "gemm_mfma16" (0/1/2), "attn_qb" (attention variant);
  * value -1 restores the default.  Returns 0, or -1 for an unknown key. */
