@@ -185,3 +185,30 @@ def test_gpu_rasterizer_full_size_properties():
     again = rz.rasterize_splats(means, quats, scales, opac, sh, c2w.to(dev), K.to(dev), W, H, sh_degree=0)
     assert torch.equal(again[0], rgb) and torch.equal(again[1], dep)
     print("full-size raster: pairs", rz.last_n_isects)
+
+
+@pytest.mark.gpu
+def test_gpu_forward_splats_render_through_model_rasterizer():
+    """The caller's flow (infer.py:259-264, GaussianSplatRenderer.render rasterization.py:221-241): forward with the
+    3D-Gaussian head -> predictions["splats"] -> model.gs_renderer.rasterizer.rasterize_batches at the predicted
+    cameras.  Checked against the oracle rasteriser on the same splats and cameras."""
+    import torch
+    from conftest import load_golden
+    from hunyuanworld_mirror_amd import WorldMirror
+    cfg, views, flags, outs, z = load_golden("tiny_gs_2v_70x70")
+    m = WorldMirror(arch=cfg).init_synthetic_weights().to("cuda:0")
+    pred = m({k: torch.from_numpy(v).cuda() for k, v in views.items()}, flags)
+    sp = pred["splats"]
+    c2w, K = pred["camera_poses"], pred["camera_intrs"]          # [1, S, 4, 4], [1, S, 3, 3]
+    H, W = views["img"].shape[-2:]
+    col, dep, al = m.gs_renderer.rasterizer.rasterize_batches(sp["means"], sp["quats"], sp["scales"], sp["opacities"], sp["sh"],
+                                                              c2w, K, width=W, height=H, sh_degree=0)
+    torch.cuda.synchronize()
+    S = views["img"].shape[1]
+    assert col.shape == (1, S, H, W, 3) and dep.shape == (1, S, H, W, 1) and al.shape == (1, S, H, W, 1)
+    assert torch.isfinite(col).all() and torch.isfinite(dep).all() and float(al.min()) >= 0 and float(al.max()) <= 1
+    vm = np.linalg.inv(c2w[0].cpu().numpy().astype(np.float64)).astype(np.float32)
+    r0, e0, a0, _ = R.rasterize(sp["means"][0].cpu().numpy(), sp["quats"][0].cpu().numpy(), sp["scales"][0].cpu().numpy(),
+                                sp["opacities"][0].cpu().numpy(), sp["sh"][0][:, 0].cpu().numpy(), vm, K[0].cpu().numpy(), W, H)
+    print("model splats rendered: coverage", float((a0 > 0.5).mean()), "rgb", rel_l2(col[0].cpu().numpy(), r0))
+    assert rel_l2(col[0].cpu().numpy(), r0) < 2e-3 and rel_l2(al[0].cpu().numpy(), a0) < 2e-3
