@@ -1251,6 +1251,17 @@ extern "C" wm_status wm_op_attention_split(int dtype, const void* Q, const void*
   }
   return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
+extern "C" size_t wm_prune_gs_workspace_bytes(size_t n) { return wm_prune_workspace_bytes(n); }
+extern "C" wm_status wm_prune_gs(const float* means, const float* quats, const float* scales, const float* opacities, const float* sh,
+                                 const float* weights, int n, float voxel_size, float* out_means, float* out_quats, float* out_scales,
+                                 float* out_opacities, float* out_sh, int* n_voxels, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n < 0 || !(voxel_size > 0.f) || !n_voxels) return WM_ERR_INVALID;
+  if (n > 0 && (!means || !quats || !scales || !sh || !weights || !out_means || !out_quats || !out_scales || !out_opacities || !out_sh || !workspace))
+    return WM_ERR_INVALID;
+  const hipError_t e = wm_launch_prune_gs(means, quats, scales, opacities, sh, weights, n, voxel_size, out_means, out_quats, out_scales,
+                                          out_opacities, out_sh, n_voxels, workspace, workspace_bytes, (hipStream_t)stream);
+  return e == hipSuccess ? WM_OK : e == hipErrorInvalidValue ? WM_ERR_INVALID : WM_ERR_HIP;
+}
 extern "C" size_t wm_rasterize_workspace_bytes(int n_gaussians, int n_cameras, int width, int height, size_t max_isects) {
   return wm_raster_workspace_bytes(n_gaussians, n_cameras, width, height, max_isects);
 }

@@ -91,29 +91,33 @@ def extract_priors(views: Dict[str, torch.Tensor]):
 
 
 def prune_gs(splats: Dict[str, torch.Tensor], voxel_size: float = 0.002) -> Dict[str, List[torch.Tensor]]:
-    """Weighted voxel merge of the per-pixel splats (rasterization.py:301-387).  Post-path geometry
-    (SURVEY §8f rank 2): torch ops on the device for now; everything before it runs in HIP."""
+    """Weighted voxel merge of the per-pixel splats (rasterization.py:301-387) through ``wm_prune_gs``
+    (splat_prune.hip: voxel keys, stable radix sort, one thread per voxel summing in index order).  Same input dict
+    ([B, n, ...] tensors incl. ``weights``) and output dict (lists over B) as the reference method."""
+    import ctypes as C
+    L = _lib.lib()
     out = {k: [] for k in ("means", "sh", "opacities", "scales", "quats")}
     for i in range(splats["means"].shape[0]):
-        mean, w = splats["means"][i], splats["weights"][i]
-        vi = (mean / voxel_size).floor().long()
-        vi = vi - vi.min(0)[0]
-        dims = vi.max(0)[0] + 1
-        flat = vi[:, 0] * dims[1] * dims[2] + vi[:, 1] * dims[2] + vi[:, 2]
-        uniq, inv = torch.unique(flat, return_inverse=True)
-        K = uniq.numel()
-        wsum = torch.zeros(K, device=w.device).scatter_add_(0, inv, w).clamp(min=1e-8)
-
-        def wavg(x):
-            acc = torch.zeros((K,) + x.shape[1:], device=x.device)
-            acc.index_add_(0, inv, x * w.reshape((-1,) + (1,) * (x.dim() - 1)))
-            return acc
-        out["means"].append(wavg(mean) / wsum[:, None])
-        out["sh"].append(wavg(splats["sh"][i]) / wsum[:, None, None])
-        out["opacities"].append(torch.zeros(K, device=w.device).scatter_add_(0, inv, w * w) / wsum)
-        out["scales"].append(wavg(splats["scales"][i]) / wsum[:, None])
-        q = wavg(splats["quats"][i])
-        out["quats"].append(q / q.norm(dim=1, keepdim=True).clamp(min=1e-8))
+        t = {k: splats[k][i].detach().to(torch.float32).contiguous() for k in ("means", "quats", "scales", "opacities", "sh", "weights")}
+        dev = t["means"].device
+        if dev.type != "cuda":
+            raise RuntimeError("prune_gs runs in libwm_hip.so on the GPU: move the splats to a HIP device")
+        n = int(t["means"].shape[0])
+        nsh = int(t["sh"].shape[1]) if t["sh"].dim() == 3 else 1
+        if nsh != 1:
+            raise NotImplementedError("degree-0 SH only (the reference merges sh[:, 0] and leaves higher bands at zero)")
+        o = {"means": torch.empty((n, 3), device=dev), "quats": torch.empty((n, 4), device=dev), "scales": torch.empty((n, 3), device=dev),
+             "opacities": torch.empty((n,), device=dev), "sh": torch.empty((n, 1, 3), device=dev)}
+        ws = torch.empty(max(int(L.wm_prune_gs_workspace_bytes(n)), 256), device=dev, dtype=torch.uint8)
+        K = C.c_int(0)
+        p = lambda x: C.c_void_p(x.data_ptr())
+        st = L.wm_prune_gs(p(t["means"]), p(t["quats"]), p(t["scales"]), p(t["opacities"]), p(t["sh"]), p(t["weights"]), n, float(voxel_size),
+                           p(o["means"]), p(o["quats"]), p(o["scales"]), p(o["opacities"]), p(o["sh"]), C.byref(K), p(ws), ws.numel(),
+                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if st != 0:
+            raise RuntimeError(f"wm_prune_gs failed with status {st}")
+        for k in out:
+            out[k].append(o[k][:K.value])
     return out
 
 

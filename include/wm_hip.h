@@ -164,6 +164,17 @@ size_t wm_confidence_mask_workspace_bytes(size_t n);
 wm_status wm_confidence_mask(const float* conf, size_t n, float conf_threshold_percent, unsigned char* mask, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* Voxel merge of the per-pixel splats — GaussianSplatRenderer.prune_gs (src/models/models/rasterization.py:301-387; called at
+ * :216 and on predictions["splats"] by the callers).  Inputs [n, ...] device fp32: means [n,3], quats [n,4], scales [n,3],
+ * opacities [n] (not read: the merged opacity is sum w^2 / sum w, as in the reference), sh [n,3] (degree-0 coefficients), weights [n].
+ * Outputs have room for n rows; *n_voxels (host) = occupied voxels K, rows [0, K) are valid and ordered by ascending voxel
+ * index (torch.unique's order).  Sums run in original index order, i.e. bit-identical to the reference on CPU.  One stream
+ * synchronisation (K is data dependent). */
+size_t wm_prune_gs_workspace_bytes(size_t n);
+wm_status wm_prune_gs(const float* means, const float* quats, const float* scales, const float* opacities, const float* sh,
+                      const float* weights, int n, float voxel_size, float* out_means, float* out_quats, float* out_scales,
+                      float* out_opacities, float* out_sh, int* n_voxels, void* workspace, size_t workspace_bytes, void* stream);
+
 /* 3D-Gaussian-splat rasteriser forward — replaces gsplat.rasterization as the reference calls it through
  * Rasterizer.rasterize_splats (src/models/models/rasterization.py:29-66; callers: GaussianSplatRenderer.render :221-241,
  * render_interpolated_video src/utils/render_utils.py:242-312 <- infer.py:264): packed, rasterize_mode "classic", pinhole,

@@ -151,3 +151,32 @@ def test_gpu_confidence_mask_full_size():
     n = conf.numel()
     us = e0.elapsed_time(e1) / 10 * 1e3
     print(f"confidence mask {n} elements: {us:.0f} us incl. workspace allocation ({6 * 4 * n / (us * 1e-6) / 1e9:.0f} GB/s over its 6 read passes)")
+
+
+# ------------------------------------------------------------------------------------------------ prune_gs (voxel merge)
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,spread", [(200000, 0.08), (5000, 3.0), (1, 1.0), (4096, 0.0005)])
+def test_gpu_prune_gs_matches_oracle(n, spread):
+    """wm_prune_gs (splat_prune.hip) against the CPU oracle (oracle/worldmirror_ref.prune_gs, itself pinned to the
+    reference's prune_gs by the tiny_gs golden): same voxel set and order (torch.unique), sums in index order -> the
+    merged attributes agree to the last bits; negative coordinates, heavy collisions (spread 0.08 / voxel 0.002: ~3
+    splats per voxel), one voxel holding everything, a single splat."""
+    import torch
+    from hunyuanworld_mirror_amd.worldmirror import prune_gs
+    from oracle import worldmirror_ref as WR
+    g = torch.Generator().manual_seed(n)
+    sp = {"means": (torch.rand(n, 3, generator=g) - 0.5) * spread + torch.tensor([0.3, -0.7, 1.1]),
+          "quats": torch.randn(n, 4, generator=g), "scales": torch.rand(n, 3, generator=g) * 0.05,
+          "opacities": torch.rand(n, generator=g), "sh": torch.randn(n, 1, 3, generator=g), "weights": torch.rand(n, generator=g) + 1e-3}
+    ref = WR.prune_gs(sp)
+    got = prune_gs({k: v[None].cuda() for k, v in sp.items()})
+    K = ref["means"].shape[0]
+    print(f"prune_gs n={n}: {K} voxels")
+    for k in ("means", "quats", "scales", "opacities", "sh"):
+        a = got[k][0].cpu()
+        assert a.shape == ref[k].shape, (k, a.shape, ref[k].shape)
+        tol = 1e-5 if k == "quats" else 2e-6   # quats: torch.norm's own reduction order in the normalisation
+        assert torch.allclose(a, ref[k], rtol=tol, atol=tol / 10), (k, float((a - ref[k]).abs().max()))
+    if n > 1000:
+        again = prune_gs({k: v[None].cuda() for k, v in sp.items()})
+        assert all(torch.equal(again[k][0], got[k][0]) for k in got)   # no float atomics: bit-exact run to run
