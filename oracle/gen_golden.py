@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--refinit", action="store_true", help="goldens with the reference's own init statistics")
     ap.add_argument("--full-priors", action="store_true", help="full architecture, 2 x 224^2, pose + intrinsics priors (the C3 flag set)")
+    ap.add_argument("--full-nonsquare", action="store_true", help="full architecture, 3 views of 154 x 210 (non-square: pos-embed resample), pose + depth + intrinsics priors")
     ap.add_argument("--full-gs", action="store_true", help="full architecture with the 3D-Gaussian head (BASELINE config 5 path, rasterisation not run), 2 x 224^2")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -188,6 +189,11 @@ def main():
         cfg = WMConfig()
         m = build_reference(cfg)
         run_case(m, cfg, "full_2v_224_pose_ray", 12, 2, 224, 224, [1, 0, 1], sub=4, keep_taps=False)
+        return
+    if a.full_nonsquare:
+        cfg = WMConfig()
+        m = build_reference(cfg)
+        run_case(m, cfg, "full_3v_154x210_allpriors", 14, 3, 154, 210, [1, 1, 1], sub=2, keep_taps=False)
         return
     if a.full_gs:
         cfg = WMConfig(enable_gs=True)

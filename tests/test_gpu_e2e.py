@@ -82,10 +82,10 @@ def test_tiny_golden_f16_backbone():
         assert e < TOL_F16[k]
 
 
-@pytest.mark.parametrize("name", ["full_2v_224_noprior", "full_2v_224_pose_ray"])
+@pytest.mark.parametrize("name", ["full_2v_224_noprior", "full_2v_224_pose_ray", "full_3v_154x210_allpriors"])
 def test_full_arch_2x224_golden(name):
-    """The full 1.23 B-parameter architecture, 2 x 224^2, against the reference's outputs: BASELINE config C1
-    (no priors) and the C3 flag set (camera-pose + intrinsics priors on)."""
+    """The full 1.23 B-parameter architecture against the reference's outputs: 2 x 224^2 BASELINE config C1 (no priors) and
+    the C3 flag set (camera-pose + intrinsics priors on); 3 x 154 x 210 (non-square) with pose + depth + intrinsics priors."""
     cfg, views, flags, outs, z = load_golden(name)
     m = _cached_model(cfg)
     got = _run(m, views, flags)
@@ -93,7 +93,7 @@ def test_full_arch_2x224_golden(name):
     errs = {}
     for k, v in outs.items():
         g = got[k].cpu().numpy()
-        if g.ndim >= 4 and g.shape[2] == 224:
+        if g.ndim >= 4 and g.shape[2] == views["img"].shape[-2]:
             g = g[:, :, ::sub, ::sub]
         assert g.shape == v.shape, k
         errs[k] = rel_l2(g, v)
@@ -104,7 +104,8 @@ def test_full_arch_2x224_golden(name):
     for k in ("pts3d", "depth", "normals"):
         s = float(got[k].double().sum())
         ref = float(z["sum_" + k])
-        assert abs(s - ref) / abs(ref) < 2e-3, (k, s, ref)
+        # signed sums: the components of unit normals cancel heavily, so their checksum is the loosest
+        assert abs(s - ref) / abs(ref) < (5e-3 if k == "normals" else 2e-3), (k, s, ref)
 
 
 @pytest.mark.parametrize("name", ["refinit_tiny_3v_70x56_pose_ray", "refinit_full_2v_224_noprior"])

@@ -97,15 +97,16 @@ def test_prune_gs_merges_voxels():
 
 
 @pytest.mark.skipif(os.environ.get("WM_SKIP_FULL_ORACLE") == "1", reason="skipped by env")
-@pytest.mark.parametrize("name", ["full_2v_224_noprior", "full_2v_224_pose_ray"])
+@pytest.mark.parametrize("name", ["full_2v_224_noprior", "full_2v_224_pose_ray", "full_3v_154x210_allpriors"])
 def test_oracle_matches_reference_full_2x224(name):
-    """Full 1.23 B-parameter architecture at 2 x 224^2: BASELINE config C1 (no priors) and the C3 flag set
-    (camera-pose + intrinsics priors on, cond_flags [1, 0, 1])."""
+    """Full 1.23 B-parameter architecture: 2 x 224^2 BASELINE config C1 (no priors) and the C3 flag set (camera-pose +
+    intrinsics priors on, cond_flags [1, 0, 1]); 3 x 154 x 210 (non-square: pos-embed resample) with all three priors."""
     cfg, o, outs, z, col = _run(name)
     sub = int(z["subsample"])
+    Himg = z["in_img"].shape[-2]
     for k, v in outs.items():
         got = o[k].numpy()
-        if got.ndim >= 4 and got.shape[2] == 224:
+        if got.ndim >= 4 and got.shape[2] == Himg:
             got = got[:, :, ::sub, ::sub]
         assert got.shape == v.shape, k
         assert rel_l2(got, v) < 2e-5, k
