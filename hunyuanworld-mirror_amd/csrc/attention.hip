@@ -700,14 +700,17 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
     else if (a.kv_chunks > 1 && lim >= 2) best = lim < 4 ? lim : 4;
     a.kv_splits = best;
     a.full_units = 0;
-    // Tail split (one GPU): the launch's last, partly filled round — e.g. 688 units on 512 slots at 8 views: 176 whole
-    // blocks, one per CU, with 80 CUs idle — is cut into S short blocks per unit, so that it fills the chip again.
+    // Tail split: the launch's last, partly filled round — e.g. 688 units on 512 slots at 8 views: 176 whole blocks, one
+    // per CU, with 80 CUs idle — is cut into S short blocks per unit, so that it fills the chip again.  It replaces the
+    // uniform split wherever the launch spans more than one round: also on the view-sharded path (8 local views against
+    // 2 / 4 / 8 gathered chunks: 1040 / 1051 / 1050 vs 1003 / 1030 / 1037 TF/s for the uniform 4-way split, with a combine
+    // pass over a quarter of the rows, tools/bench_attn_split_chunks.py).
     // Model, in units of a full round: a partial round whose blocks sit alone on their CU runs 1.37x faster (measured:
     // one wave per SIMD is 1.46x slower per wave); a slice costs 1 / S; the combine pass ~0.01 per slice.  Measured
     // (tools/bench_attn_tail.py): 8 views 530 -> 480-495 us (+8-10 %), 16 views +8 %, 32 views +4-7 %; the short
     // per-frame sequences (22 key tiles) lose 10 % and are left alone (ntiles >= 64).
     const long tail = blocks % slots;
-    if (a_in.kv_splits == 0 && best == 1 && lim >= 2 && a.kv_chunks == 1 && ntiles >= 64 && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
+    if (a_in.kv_splits == 0 && wm_tuning[WM_TUNE_ATTN_SPLITS] <= 0 && lim >= 2 && ntiles >= 64 && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
       auto round_cost = [&](long n) { const long rem = n % slots; return (double)(n / slots) + (rem == 0 ? 0.0 : rem * 2 <= slots ? 0.73 : 1.0); };
       double best_cost = round_cost(tail);
       int bs = 1;
@@ -717,6 +720,7 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
       }
       if (wm_tuning[WM_TUNE_ATTN_TAIL] > 1) bs = wm_tuning[WM_TUNE_ATTN_TAIL] < lim ? wm_tuning[WM_TUNE_ATTN_TAIL] : lim;  // A/B: forced slice count
       if (bs > 1) { a.kv_splits = bs; a.full_units = (int)(blocks - tail); }
+      else if (best > 1) a.kv_splits = best;  // keep the uniform choice
     }
   }
   const int units = tiles_per_seq * nseq * a.H;

@@ -269,8 +269,8 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("H16", Mx * 4 * D * 2);
   for (int i = 0; i < 4; ++i) add(("tap" + std::to_string(i)).c_str(), Mv * 2 * D * 4);
   add("KVG", (size_t)d.world * 2 * Mv * D * 2);
-  add("ATT_PO", (size_t)(d.world > 1 ? 4 : WM_ATTN_MAX_SPLITS) * Mx * D * 4);   // split-KV attention partials (sharded path: 4 slices; one GPU: the tail round, up to 8): unnormalised O, (max, sum)
-  add("ATT_ML", (size_t)(d.world > 1 ? 4 : WM_ATTN_MAX_SPLITS) * Mx * (D / 64) * 2 * 4);
+  add("ATT_PO", (size_t)WM_ATTN_MAX_SPLITS * Mx * D * 4);   // split-KV attention partials (tail round of a launch cut into up to 8 key slices; uniform 4-way split when a sharded launch fits one round): unnormalised O, (max, sum)
+  add("ATT_ML", (size_t)WM_ATTN_MAX_SPLITS * Mx * (D / 64) * 2 * 4);
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("dino_pos", (size_t)(1 + d.hw) * D * 4);
@@ -753,7 +753,7 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     } else {
       a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
     }
-    a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = d.world > 1 ? 4 : WM_ATTN_MAX_SPLITS;
+    a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
     ProfScope ps(h, is_global ? 0 : 1, c.s);
     LCHK(c, wm_launch_attention(a, c.s));
   }
