@@ -175,10 +175,10 @@ class WorldMirror:
         m = cls(**{**cfg, **kw})
         from safetensors import safe_open
         sd = {}
-        with safe_open(os.path.join(path, "model.safetensors"), framework="np") as f:
+        with safe_open(os.path.join(path, "model.safetensors"), framework="pt", device="cpu") as f:  # "pt": bf16 / f16 checkpoints too
             for k in f.keys():
                 sd[k] = f.get_tensor(k)
-        m.load_state_dict(sd, strict=False)
+        m.load_state_dict(sd, strict=False)  # PyTorchModelHubMixin loads non-strictly: missing -> init value, unexpected -> ignored
         return m
 
     def load_state_dict(self, sd, strict: bool = False):

@@ -78,3 +78,37 @@ def test_param_spec_counts():
     assert abs(n - 1.230e9) / 1.230e9 < 2e-3          # 1.230 B parameters without GS
     n_gs = sum(int(np.prod(s)) for s in param_spec(WMConfig(enable_gs=True)).values())
     assert abs(n_gs - 1.263e9) / 1.263e9 < 2e-3
+
+
+def test_from_pretrained_local_dir(tmp_path):
+    """WorldMirror.from_pretrained(<local dir>) (infer.py:95 / app.py:104 with a local path; PyTorchModelHubMixin layout:
+    config.json = ctor kwargs, model.safetensors): fp32 and bf16 tensors, an unexpected key (ignored) and a missing key
+    (reported, left at its init value) — no GPU needed, the weights stay on the host until .to()."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from hunyuanworld_mirror_amd import WorldMirror, WMConfig
+    from hunyuanworld_mirror_amd.weights import iter_params
+    cfg = WMConfig.tiny()
+    kw = dict(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, gs_dim=cfg.gs_dim, enable_cond=True, enable_cam=True,
+              enable_pts=True, enable_depth=True, enable_norm=True, enable_gs=False, patch_embed="dinov2_vitl14_reg", fixed_patch_embed=False,
+              sampling_strategy="uniform", dpt_gradient_checkpoint=False, condition_strategy=["token", "pow3r", "token"],
+              enable_interpolation=False, max_resolution=2044)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in iter_params(cfg)}
+    names = sorted(sd)
+    dropped, as_bf16 = names[3], names[5]
+    ref_bf16 = sd[as_bf16].to(torch.bfloat16)
+    sd[as_bf16] = ref_bf16
+    del sd[dropped]
+    sd["not.a.parameter"] = torch.zeros(3)
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(kw))
+    save_file(sd, str(d / "model.safetensors"))
+    m = WorldMirror.from_pretrained(str(d), arch=cfg)   # arch: the scaled-down test architecture behind the same kwargs
+    assert dropped not in m._host_weights and "not.a.parameter" not in m._host_weights
+    assert np.array_equal(m._host_weights[as_bf16], ref_bf16.float().numpy())
+    k0 = names[0]
+    assert np.array_equal(m._host_weights[k0], sd[k0].numpy())
+    with pytest.raises(FileNotFoundError):
+        WorldMirror.from_pretrained("tencent/HunyuanWorld-Mirror")   # a hub name: no network here, local directories only
