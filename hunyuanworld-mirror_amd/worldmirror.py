@@ -131,6 +131,9 @@ class _GSRenderer:
         self.rasterizer = Rasterizer()
         self.enable_prune, self.voxel_size, self.sh_degree = True, 0.002, 0
 
+    def prune_gs(self, splats, voxel_size: float = 0.002):  # rasterization.py:301 (render_utils.py:206 calls it on the renderer)
+        return prune_gs(splats, voxel_size)
+
 
 class WorldMirror:
     """Drop-in for the reference WorldMirror (ctor kwargs: worldmirror.py:17-34)."""
