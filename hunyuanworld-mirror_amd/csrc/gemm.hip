@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -58,6 +58,17 @@ __device__ __forceinline__ void stage_piece(const u16* __restrict__ g, int ld, i
 
 __device__ __forceinline__ s16x8 lds_frag(const char* tile, int row, int chunk) {
   return *(const s16x8*)(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+// logical tile id -> (row band, column tile).  With more than 4 column tiles the tiles that run together on an XCD (32 CUs,
+// consecutive ids) are arranged as G row bands x 8 column tiles instead of 2 x 16: per round the XCD's L2 then fetches
+// (G x A band + 32 / G x W slab) instead of (2 x A + 16 x W) — e.g. fc1 at 8 views 144 instead of 216 MB of L2 misses.
+__device__ __forceinline__ void tile_of(int lid, int ntm, int ntn, int G, int& band, int& nt) {
+  if (G <= 1 || ntn <= 4) { band = lid / ntn; nt = lid - band * ntn; return; }
+  const int per = G * ntn, sg = lid / per, r = lid - sg * per;
+  const int here = ntm - sg * G < G ? ntm - sg * G : G;
+  nt = r / here;
+  band = sg * G + (r - nt * here);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -786,7 +797,9 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+  int band, nt;
+  tile_of(lid, ntm, ntn, p.group_bands, band, nt);
+  const int m0 = band * BM, n0 = nt * BN;
   const int l15 = lane & 15, lq = lane >> 4;
   const bool two = QI == 4 || wave < 4;  // this wave carries two A pieces per region (wave-uniform)
 
@@ -1057,12 +1070,16 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
   if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
   const int cfg = pick_cfg(a);
+  const int gb = wm_tuning[WM_TUNE_GEMM_GROUP] >= 0 ? wm_tuning[WM_TUNE_GEMM_GROUP] : 4;
   if (a.epi == WM_EPI_QKV) {
     if (a.qkv.tokens_per_view <= 0 || a.qkv.grid_w <= 0 || a.M >= (1 << 20) || a.qkv.tokens_per_view >= (1 << 16)) return hipErrorInvalidValue;
     WmGemmArgs b = a;
+    b.group_bands = gb;
     b.qkv.inv_tpv = 1.0f / (float)a.qkv.tokens_per_view;
     b.qkv.inv_gw = 1.0f / (float)a.qkv.grid_w;
     return b.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(b, cfg, s) : launch_T<WM_T_F16>(b, cfg, s);
   }
-  return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, cfg, s) : launch_T<WM_T_F16>(a, cfg, s);
+  WmGemmArgs c = a;
+  c.group_bands = gb;
+  return c.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(c, cfg, s) : launch_T<WM_T_F16>(c, cfg, s);
 }

@@ -9,7 +9,8 @@ p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def tune(k, v): assert L.wm_set_tuning(k.encode(), v) == 0
 def rel(a, b): return float((a.double() - b.double()).norm() / b.double().norm())
-cands = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(4, 1), (5, 1), (7, 0), (8, 0)]
+cands = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(4, 1), (5, 1)]
+GROUPS = (1, 4)  # gemm_group: row bands per L2 supertile
 for cfg, pp in cands:
     tune("gemm_cfg", cfg); tune("gemm_pp", pp)
     for (M, N, K) in [(256, 256, 64), (1000, 384, 640), (2752, 1024, 1024), (777, 4096, 1024), (300, 64, 192)]:
@@ -34,11 +35,12 @@ for M in (11008, 44032):
         res = {}
         for rep in range(2):
             for cfg, pp in cands:
-                tune("gemm_cfg", cfg); tune("gemm_pp", pp)
+              for gb in GROUPS:
+                tune("gemm_cfg", cfg); tune("gemm_pp", pp); tune("gemm_group", gb)
                 for _ in range(2): L.wm_op_gemm(0, epi, p(A), p(W), p(Cc), p(bias), p(gamma), M, N, K, s)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(10): L.wm_op_gemm(0, epi, p(A), p(W), p(Cc), p(bias), p(gamma), M, N, K, s)
                 e1.record(); torch.cuda.synchronize()
-                res.setdefault(f"cfg{cfg}pp{pp}", []).append(round(2 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9))
+                res.setdefault(f"cfg{cfg}pp{pp}g{gb}", []).append(round(2 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9))
         print(json.dumps({"M": M, "gemm": name, "tflops": res}), flush=True)
