@@ -13,7 +13,7 @@ for name, H, M, Ls in cases:
     v = torch.randn(H, M, 64, device=dev).to(torch.bfloat16); o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
     fl = 4.0 * M * Ls * 64 * H
     res = {}; outs = {}
-    for rep in range(2):
+    for rep in range(int(__import__('os').environ.get('REPS', '2'))):
         for qb in variants:
             assert L.wm_set_tuning(b"attn_qb", qb) == 0
             for _ in range(2): L.wm_op_attention(0, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, s)
