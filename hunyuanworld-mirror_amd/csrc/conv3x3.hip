@@ -659,7 +659,10 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   if (wm_tuning[WM_TUNE_CONV_BN] > 0) bn = wm_tuning[WM_TUNE_CONV_BN];
   const bool rs_ok = (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0;
   const bool rs = rs_ok && a.up_hs == 0;  // register-staged main loop (plain input, even chunk count)
-  if (rs_ok && a.up_hs > 0 && bn == 128) return launch_rs<T, 4, 2, 2, 2, 1>(a, s);  // fused resize, 128-channel tile
+  if (rs_ok && a.up_hs > 0 && bn == 128) {  // fused resize, 128-channel tile
+    if (wm_tuning[WM_TUNE_CONV_TPX] == 32) return launch_rs<T, 4, 2, 2, 2, 1, 32>(a, s);  // A/B: 32 x 8 pixel tile (no LDS bank conflicts, 2.5 % more tiles at 296^2)
+    return launch_rs<T, 4, 2, 2, 2, 1>(a, s);
+  }
   if (rs && bn >= 128 && wm_tuning[WM_TUNE_CONV_TPX] != 16) {
     // pixel-tile shape: rounds over the CUs (one block per CU) with 16 x 16 vs 32 x 8 tiles
     const long ct = (a.Cout + bn - 1) / bn;
