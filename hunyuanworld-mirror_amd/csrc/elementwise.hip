@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ s
 }
 
 // F.interpolate(mode="bilinear", align_corners=True) on NHWC f32 (dense_head.py:217-225,535)
-__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int Hi,
+// OUT16 = 0: fp32 out.  OUT16 = 1 / 2: bf16 / f16 out (the operand of conv_n32.hip: rounded exactly where the fused-resize conv rounds)
+template <int OUT16>
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ in, void* __restrict__ outp, int N, int Hi,
                                                        int Wi, int Ho, int Wo, int C4, const float* __restrict__ addx,
                                                        const float* __restrict__ addy) {
   const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
@@ -299,7 +301,15 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
       const float4 a = c < half ? *(const float4*)(addx + (size_t)x * half + c) : *(const float4*)(addy + (size_t)y * half + (c - half));
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
-    *(float4*)(out + (((size_t)n * Ho + y) * Wo + x) * C + c) = o;
+    const size_t oi = (((size_t)n * Ho + y) * Wo + x) * C + c;
+    if constexpr (OUT16 == 0) {
+      *(float4*)((float*)outp + oi) = o;
+    } else {
+      uint2 u;
+      if constexpr (OUT16 == 1) { u.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16); u.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16); }
+      else { u.x = (uint32_t)f2h(o.x) | ((uint32_t)f2h(o.y) << 16); u.y = (uint32_t)f2h(o.z) | ((uint32_t)f2h(o.w) << 16); }
+      *(uint2*)((u16*)outp + oi) = u;
+    }
   }
 }
 
@@ -431,7 +441,17 @@ hipError_t wm_launch_bilinear(const float* in, float* out, int N, int Hi, int Wi
   if (C % 8) return hipErrorInvalidValue;
   const size_t total = (size_t)N * Ho * Wo * (C / 4);
   if (!total) return hipSuccess;
-  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, Hi, Wi, Ho, Wo, C / 4, addx, addy);
+  hipLaunchKernelGGL(bilinear_kernel<0>, dim3(grid_for(total)), dim3(256), 0, s, in, (void*)out, N, Hi, Wi, Ho, Wo, C / 4, addx, addy);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_bilinear16(const float* in, void* out16, int N, int Hi, int Wi, int Ho, int Wo, int C, const float* addx,
+                                const float* addy, int dtype, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  if (!total) return hipSuccess;
+  if (dtype == WM_T_BF16) hipLaunchKernelGGL(bilinear_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, in, out16, N, Hi, Wi, Ho, Wo, C / 4, addx, addy);
+  else hipLaunchKernelGGL(bilinear_kernel<2>, dim3(grid_for(total)), dim3(256), 0, s, in, out16, N, Hi, Wi, Ho, Wo, C / 4, addx, addy);
   return hipGetLastError();
 }
 

@@ -126,6 +126,15 @@ struct WmConvArgs {
   const float* up_addx; const float* up_addy;
 };
 bool wm_conv3x3_applicable(const WmConvArgs& a);
+// 3x3 / s1 / p1 conv with 32 output channels on a 16-bit NHWC input (conv_n32.hip); zero: >= 16 B of device zeros
+struct WmConvN32Args {
+  const uint16_t* x; const uint16_t* w; const float* bias; float* y; const uint16_t* zero;
+  int N, H, W, Cin, relu_out, dtype;
+};
+hipError_t wm_launch_conv3x3_n32_in16(const WmConvN32Args& a, hipStream_t s);
+// F.interpolate(bilinear, align_corners) (+ separable position tables) written as 16-bit NHWC (elementwise.hip)
+hipError_t wm_launch_bilinear16(const float* in, void* out16, int N, int Hi, int Wi, int Ho, int Wo, int C, const float* addx,
+                                const float* addy, int dtype, hipStream_t s);
 hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ camera head / small fp32 ops (small.hip)

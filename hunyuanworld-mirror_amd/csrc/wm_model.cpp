@@ -1251,6 +1251,22 @@ extern "C" wm_status wm_op_attention_split(int dtype, const void* Q, const void*
   }
   return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
+// resize (align_corners bilinear + position tables) to 16 bits, then the 32-channel 3x3 conv on it: the unfused form of
+// wm_op_conv3x3_up for Cout == 32.  up16: Hi * Wi * N * Cin 16-bit elements + 16 B of scratch (zeroed here).
+extern "C" wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi,
+                                       int Wi, int Cin, const float* addx, const float* addy, int relu_out, void* up16, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin % 64 || !up16) return WM_ERR_INVALID;
+  const size_t n16 = (size_t)N * Hi * Wi * Cin;
+  uint16_t* zero = (uint16_t*)up16 + ((n16 + 7) & ~(size_t)7);
+  if (hipMemsetAsync(zero, 0, 16, s) != hipSuccess) return WM_ERR_HIP;
+  if (wm_launch_bilinear16(x, up16, N, Hs, Ws, Hi, Wi, Cin, addx, addy, dtype, s) != hipSuccess) return WM_ERR_HIP;
+  WmConvN32Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const uint16_t*)up16; a.w = (const uint16_t*)w16; a.bias = bias; a.y = y; a.zero = zero;
+  a.N = N; a.H = Hi; a.W = Wi; a.Cin = Cin; a.relu_out = relu_out; a.dtype = dtype;
+  return wm_launch_conv3x3_n32_in16(a, s) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
 extern "C" size_t wm_prune_gs_workspace_bytes(size_t n) { return wm_prune_workspace_bytes(n); }
 extern "C" wm_status wm_prune_gs(const float* means, const float* quats, const float* scales, const float* opacities, const float* sh,
                                  const float* weights, int n, float voxel_size, float* out_means, float* out_quats, float* out_scales,

@@ -164,6 +164,13 @@ size_t wm_confidence_mask_workspace_bytes(size_t n);
 wm_status wm_confidence_mask(const float* conf, size_t n, float conf_threshold_percent, unsigned char* mask, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* Operator-level entry (parity tests / A-B): F.interpolate(x, (Hi, Wi), bilinear, align_corners=True) (+ separable position tables
+ * addx [Wi][Cin/2], addy [Hi][Cin/2], may be NULL) rounded to the 16-bit operand type, then Conv2d(Cin, 32, 3, padding=1) (+ ReLU):
+ * the un-fused form the DPT tail uses for output_conv2[0] (dense_head.py:97-105,217-251).  up16: caller-owned device scratch of
+ * N*Hi*Wi*Cin 16-bit elements + 32 bytes. */
+wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi,
+                            int Wi, int Cin, const float* addx, const float* addy, int relu_out, void* up16, void* stream);
+
 /* Voxel merge of the per-pixel splats — GaussianSplatRenderer.prune_gs (src/models/models/rasterization.py:301-387; called at
  * :216 and on predictions["splats"] by the callers).  Inputs [n, ...] device fp32: means [n,3], quats [n,4], scales [n,3],
  * opacities [n] (not read: the merged opacity is sum w^2 / sum w, as in the reference), sh [n,3] (degree-0 coefficients), weights [n].

@@ -431,6 +431,39 @@ def test_conv3x3_wide_pixel_tile(dev, Cin, Cout, Hh, Ww):
     assert torch.equal(outs[16], outs[32])  # same accumulation order per output element
 
 
+@pytest.mark.parametrize("N,Hs,Ws,Hi,Wi,Cin", [(2, 20, 16, 35, 28, 64), (3, 40, 32, 70, 56, 128), (1, 9, 11, 33, 40, 128), (2, 74, 74, 130, 130, 128)])
+def test_up_conv_n32_unfused(dev, N, Hs, Ws, Hi, Wi, Cin):
+    """wm_op_up_conv_n32: align_corners resize (+ position tables) written as f16, then the 32-channel 3x3 conv fed by LDS-DMA
+    (conv_n32.hip, persistent blocks, deferred stores) — against fp32 torch on the same f16-rounded operands and against the
+    fused-resize kernel (wm_op_conv3x3_up); ragged tiles, more tiles than blocks (130^2: 81 tiles per image), bit-exact repeat."""
+    g = torch.Generator().manual_seed(N + Hs + Cin)
+    x = torch.randn(N, Hs, Ws, Cin, generator=g).to(dev)
+    w = (torch.randn(32, 3, 3, Cin, generator=g) / math.sqrt(9 * Cin)).half().to(dev)
+    b = torch.randn(32, generator=g).to(dev)
+    ax = torch.randn(Wi, Cin // 2, generator=g).to(dev); ay = torch.randn(Hi, Cin // 2, generator=g).to(dev)
+    y1 = torch.empty(N, Hi, Wi, 32, device=dev); y2 = torch.full((N, Hi, Wi, 32), float("nan"), device=dev)
+    up16 = torch.empty(N * Hi * Wi * Cin + 64, device=dev, dtype=torch.int16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L_ = _lib()
+    assert L_.wm_op_conv3x3_up(F16, _p(x), _p(w.view(torch.int16)), _p(b), _p(y1), N, Hs, Ws, Hi, Wi, Cin, 32, _p(ax), _p(ay), s) == 0
+    for relu in (0, 1):
+        assert L_.wm_op_up_conv_n32(F16, _p(x), _p(w.view(torch.int16)), _p(b), _p(y2), N, Hs, Ws, Hi, Wi, Cin, _p(ax), _p(ay), relu, _p(up16), s) == 0
+        torch.cuda.synchronize()
+        xr = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(Hi, Wi), mode="bilinear", align_corners=True)
+        pos = torch.cat([ax.t()[:, None, :].expand(Cin // 2, Hi, Wi), ay.t()[:, :, None].expand(Cin // 2, Hi, Wi)], 0)
+        ref = torch.nn.functional.conv2d((xr + pos[None]).half().float(), w.float().permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+        if relu:
+            ref = torch.relu(ref)
+        assert torch.isfinite(y2).all()
+        assert _rel(y2, ref) < 5e-5, _rel(y2, ref)   # one f16 rounding of an interpolated value may flip between the two arithmetic orders
+        if not relu:
+            assert _rel(y2, y1) < 5e-5
+        again = y2.clone()
+        assert L_.wm_op_up_conv_n32(F16, _p(x), _p(w.view(torch.int16)), _p(b), _p(y2), N, Hs, Ws, Hi, Wi, Cin, _p(ax), _p(ay), relu, _p(up16), s) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(again, y2)
+
+
 @pytest.mark.parametrize("Cin,Cout,Hs,Ws,Hi,Wi,pos", [(256, 128, 20, 16, 40, 32, False), (128, 32, 40, 32, 70, 56, True),
                                                     (64, 64, 9, 11, 33, 40, True), (256, 128, 148, 148, 296, 296, False)])
 def test_conv3x3_fused_upsample(dev, Cin, Cout, Hs, Ws, Hi, Wi, pos):
