@@ -271,6 +271,7 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("KVG", (size_t)d.world * 2 * Mv * D * 2);
   add("ATT_PO", (size_t)WM_ATTN_MAX_SPLITS * Mx * D * 4);   // split-KV attention partials (tail round of a launch cut into up to 8 key slices; uniform 4-way split when a sharded launch fits one round): unnormalised O, (max, sum)
   add("ATT_ML", (size_t)WM_ATTN_MAX_SPLITS * Mx * (D / 64) * 2 * 4);
+  add("ZERO256", 256);  // zero page for the out-of-image halo pieces of the DMA-fed conv (conv_n32.hip); cleared at the start of every forward
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("dino_pos", (size_t)(1 + d.hw) * D * 4);
@@ -958,7 +959,20 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     float* fused = others[1];
     const float* posx = B<float>(h, is_gs ? "gs_posx" : "dpt_posx");
     const float* posy = B<float>(h, is_gs ? "gs_posy" : "dpt_posy");
-    if (fuse_up2) {  // (the GS branch also needs the resized tensor itself: input_merger accumulates into it)
+    // output_conv2[0] un-fused (measured: 16-bit LDS-tiled resize 260 us + DMA-fed 32-channel conv 255 us vs 600-630 us for the
+    // fused-resize kernel at 8 views, tools/bench_up_conv_n32.py): resize into `fused` as 16-bit, conv reads it by LDS-DMA
+    static const int up2_env = [] { const char* e = getenv("WM_UP2_UNFUSED"); return e ? atoi(e) : 1; }();
+    const Weight* w_oc2 = W(h, sc + "output_conv2.0.weight");
+    const bool up2_unfused = up2_env && !is_gs && (F_ / 2) % 64 == 0 && F_ / 2 <= 128 && w_oc2 && w_oc2->shape[0] == 32 && w_oc2->w16 != nullptr;
+    if (up2_unfused) {
+      LCHK(c, wm_launch_bilinear16(others[0], fused, n, H8, W8, Ho, Wo, F_ / 2, posx, posy, c.hdt, c.s));
+      WmConvN32Args a;
+      memset(&a, 0, sizeof(a));
+      a.x = (const uint16_t*)fused; a.w = (const uint16_t*)w_oc2->w16; a.bias = F(h, sc + "output_conv2.0.bias"); a.y = others[2];
+      a.zero = B<uint16_t>(h, "ZERO256"); a.N = n; a.H = Ho; a.W = Wo; a.Cin = F_ / 2; a.relu_out = 0; a.dtype = c.hdt;  // the ReLU is dpt_tail's
+      ProfScope ps(h, 3, c.s);
+      LCHK(c, wm_launch_conv3x3_n32_in16(a, c.s));
+    } else if (fuse_up2) {  // (the GS branch also needs the resized tensor itself: input_merger accumulates into it)
       st = conv(c, others[0], sc + "output_conv2.0", true, nullptr, false, nullptr, others[2], n, Ho, Wo, 3, 1, 1, false, H8, W8, posx, posy);
     } else {
       LCHK(c, wm_launch_bilinear(others[0], fused, n, H8, W8, Ho, Wo, F_ / 2, posx, posy, c.s));
@@ -1009,6 +1023,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   if (st) return st;
   for (int k = 0; k < 5; ++k) h->ev_used[k] = 0;
   ProfScope whole(h, 4, s);
+  HIPCHK(h, hipMemsetAsync(B<char>(h, "ZERO256"), 0, 256, s));
   const int D = d.D;
   const std::string v = "visual_geometry_transformer.", dn = v + "patch_embed.";
   float* Xd = B<float>(h, "Xd");
