@@ -88,10 +88,31 @@ __global__ __launch_bounds__(512) void conv3x3_n32_in16_kernel(const WmConvN32Ar
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc[e] = 0.f; outv[e] = 0.f; }
   int out_tile = -1;  // block-uniform: tile whose finished accumulators wait in outv
+  // optional fused tail (dense_head.py:97-105,297-344): ReLU -> 1x1 conv 32 -> C -> split (attr C - 1, conf) -> activations; a lane
+  // holds 16 of its pixel's 32 channels (the other 16 sit in lane ^ 32), so the 1x1 conv is a 16-term dot product + one cross-half sum
+  const bool tail = p.tail_w != nullptr;
+  float tw[4][16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tw[c][4 * g + e] = (tail && c < p.tail_C) ? p.tail_w[c * 32 + 8 * g + h4 + e] : 0.f;
+  float tres[4] = {0.f, 0.f, 0.f, 0.f};  // fused tail: up to 3 attributes + confidence of this lane's pixel
   auto flush = [&]() {
     int n, y0, x0;
     tile_origin(out_tile, n, y0, x0);
     const int y = y0 + (r >> 4), x = x0 + (r & 15);
+    if (tail) {  // block-uniform: the values were finished when the tile completed; only the stores are left
+      if (y < H && x < W && (lane >> 5) == 0) {
+        const size_t i = ((size_t)n * H + y) * W + x;
+        const int A = p.tail_C - 1;
+        for (int c = 0; c < A; ++c) p.tail_attr[i * A + c] = tres[c];
+        p.tail_conf[i] = tres[3];
+      }
+      out_tile = -1;
+      return;
+    }
     if (y < H && x < W) {
       float* o = p.y + (((size_t)n * H + y) * W + x) * 32 + h4;
 #pragma unroll
@@ -126,8 +147,38 @@ __global__ __launch_bounds__(512) void conv3x3_n32_in16_kernel(const WmConvN32Ar
       }
     }
     const int j = s / nchunks;
-    if (s - j * nchunks == nchunks - 1) {  // last chunk of the tile: hand the accumulators to the deferred store
-      outv = acc;
+    if (s - j * nchunks == nchunks - 1) {  // last chunk of the tile: hand the results to the deferred store
+      if (tail) {  // finish the head here, under the DMA flight of the next chunk: ReLU, 1x1 conv, activations
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bias_e = e == 0 ? bs[g].x : e == 1 ? bs[g].y : e == 2 ? bs[g].z : bs[g].w;
+            const float v = fmaxf(acc[4 * g + e] + bias_e, 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] += v * tw[c][4 * g + e];
+          }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = xhalf_sum(o[c]) + (c < p.tail_C ? p.tail_b[c] : 0.f);  // all lanes take part
+        const int A = p.tail_C - 1;
+        if (p.tail_act == WM_ACT_NORM) {
+          float nn = 0.f;
+          for (int c = 0; c < A; ++c) nn += o[c] * o[c];
+          nn = sqrtf(nn);
+          for (int c = 0; c < A; ++c) tres[c] = o[c] / nn;
+        } else if (p.tail_act == WM_ACT_EXP) {
+          for (int c = 0; c < A; ++c) tres[c] = expf(o[c]);
+        } else {
+          for (int c = 0; c < A; ++c) {
+            const float e = expm1f(fabsf(o[c]));
+            tres[c] = o[c] > 0.f ? e : (o[c] < 0.f ? -e : 0.f);
+          }
+        }
+        tres[3] = 1.0f + expf(o[A]);
+      } else {
+        outv = acc;
+      }
       out_tile = j;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -140,7 +191,8 @@ __global__ __launch_bounds__(512) void conv3x3_n32_in16_kernel(const WmConvN32Ar
 
 hipError_t wm_launch_conv3x3_n32_in16(const WmConvN32Args& a, hipStream_t s) {
   if (a.N <= 0) return hipSuccess;
-  if (a.Cin % 64 || a.Cin <= 0 || a.Cin > 64 * MAXCH || !a.x || !a.w || !a.y || !a.zero) return hipErrorInvalidValue;
+  if (a.Cin % 64 || a.Cin <= 0 || a.Cin > 64 * MAXCH || !a.x || !a.w || !a.zero) return hipErrorInvalidValue;
+  if (a.tail_w ? (!a.tail_b || !a.tail_attr || !a.tail_conf || a.tail_C < 2 || a.tail_C > 4) : !a.y) return hipErrorInvalidValue;
   static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
   const int ntiles = a.N * ((a.H + TP - 1) / TP) * ((a.W + TP - 1) / TP);
   const int grid = ntiles < ncu ? ntiles : ncu;

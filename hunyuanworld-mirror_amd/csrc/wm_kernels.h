@@ -130,6 +130,8 @@ bool wm_conv3x3_applicable(const WmConvArgs& a);
 struct WmConvN32Args {
   const uint16_t* x; const uint16_t* w; const float* bias; float* y; const uint16_t* zero;
   int N, H, W, Cin, relu_out, dtype;
+  // optional fused DPT tail (replaces y): ReLU -> 1x1 conv 32 -> tail_C (fp32 weights [tail_C][32], bias) -> activations (WM_ACT_*)
+  const float* tail_w; const float* tail_b; float* tail_attr; float* tail_conf; int tail_C, tail_act;
 };
 hipError_t wm_launch_conv3x3_n32_in16(const WmConvN32Args& a, hipStream_t s);
 // F.interpolate(bilinear, align_corners) (+ separable position tables) written as 16-bit NHWC (elementwise.hip)

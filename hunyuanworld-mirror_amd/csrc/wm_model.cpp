@@ -961,6 +961,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     const float* posy = B<float>(h, is_gs ? "gs_posy" : "dpt_posy");
     // output_conv2[0] un-fused (measured: 16-bit LDS-tiled resize 260 us + DMA-fed 32-channel conv 255 us vs 600-630 us for the
     // fused-resize kernel at 8 views, tools/bench_up_conv_n32.py): resize into `fused` as 16-bit, conv reads it by LDS-DMA
+    bool tail_done = false;
     static const int up2_env = [] { const char* e = getenv("WM_UP2_UNFUSED"); return e ? atoi(e) : 1; }();
     const Weight* w_oc2 = W(h, sc + "output_conv2.0.weight");
     const bool up2_unfused = up2_env && !is_gs && (F_ / 2) % 64 == 0 && F_ / 2 <= 128 && w_oc2 && w_oc2->shape[0] == 32 && w_oc2->w16 != nullptr;
@@ -969,9 +970,13 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       WmConvN32Args a;
       memset(&a, 0, sizeof(a));
       a.x = (const uint16_t*)fused; a.w = (const uint16_t*)w_oc2->w16; a.bias = F(h, sc + "output_conv2.0.bias"); a.y = others[2];
-      a.zero = B<uint16_t>(h, "ZERO256"); a.N = n; a.H = Ho; a.W = Wo; a.Cin = F_ / 2; a.relu_out = 0; a.dtype = c.hdt;  // the ReLU is dpt_tail's
+      a.zero = B<uint16_t>(h, "ZERO256"); a.N = n; a.H = Ho; a.W = Wo; a.Cin = F_ / 2; a.relu_out = 0; a.dtype = c.hdt;
+      // ... with the head's tail (ReLU, 1x1 conv 32 -> C, activations) in its epilogue: the 32-channel tensor is never stored
+      a.tail_w = F(h, sc + "output_conv2.2.weight"); a.tail_b = F(h, sc + "output_conv2.2.bias"); a.tail_C = out_dim; a.tail_act = act;
+      a.tail_attr = out_attr + (size_t)v0 * Ho * Wo * (out_dim - 1); a.tail_conf = out_conf + (size_t)v0 * Ho * Wo;
       ProfScope ps(h, 3, c.s);
       LCHK(c, wm_launch_conv3x3_n32_in16(a, c.s));
+      tail_done = true;
     } else if (fuse_up2) {  // (the GS branch also needs the resized tensor itself: input_merger accumulates into it)
       st = conv(c, others[0], sc + "output_conv2.0", true, nullptr, false, nullptr, others[2], n, Ho, Wo, 3, 1, 1, false, H8, W8, posx, posy);
     } else {
@@ -980,8 +985,9 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     }
     if (st) return st;
     const size_t npix = (size_t)n * Ho * Wo, voff = (size_t)v0 * Ho * Wo;
-    LCHK(c, wm_launch_dpt_tail(others[2], F(h, sc + "output_conv2.2.weight"), F(h, sc + "output_conv2.2.bias"),
-                               out_attr + voff * (out_dim - 1), out_conf + voff, npix, out_dim, act, c.s));
+    if (!tail_done)
+      LCHK(c, wm_launch_dpt_tail(others[2], F(h, sc + "output_conv2.2.weight"), F(h, sc + "output_conv2.2.bias"),
+                                 out_attr + voff * (out_dim - 1), out_conf + voff, npix, out_dim, act, c.s));
     if (is_gs && out->splat_means) {
       // dense_head.py:232-244: fused += ReLU(conv7x7(img)); then GaussianSplatRenderer.gs_head
       // (rasterization.py:149-153): conv3x3 (no bias) -> ReLU -> conv1x1 -> 12 raw parameters per pixel
