@@ -59,9 +59,10 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("WM_BENCH_CORES", "16"))))
 
 
-def cpu_baseline(cfg, H, W, budget_views=1):
-    """CPU oracle (oracle/worldmirror_ref.py, a port of the reference's fp32 path) on the host cores,
-    on a bounded sample of the same workload: `budget_views` views at the same resolution."""
+def cpu_baseline(cfg, H, W, budget_views=8):
+    """CPU oracle (oracle/worldmirror_ref.py, a port of the reference's fp32 path) on the host cores, on the SAME workload
+    as the GPU line at N = 1 (BASELINE C2: all 8 views, so the cross-view attention over 11 008 keys is included);
+    `--cpu-views 1` gives the cheaper 1-view sample (about 8 s instead of about 70 s on 16 cores)."""
     from hunyuanworld_mirror_amd.weights import iter_params
     from oracle import worldmirror_ref as R
     cores = host_cores()
@@ -91,6 +92,8 @@ def main():
     ap.add_argument("--priors", action="store_true",
                     help="camera-pose + intrinsics priors on (BASELINE config C3: --views-per-gpu 32 --priors), cond_flags [1, 0, 1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=8, help="views of the CPU-baseline sample (8 = the C2 workload itself)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the C3 (32 views, priors) leg that follows the timed region at N = 1")
     ap.add_argument("--tiny", action="store_true", help="scaled-down architecture (plumbing check only)")
     a = ap.parse_args()
 
@@ -116,17 +119,22 @@ def main():
     log("weights ready")
     if world > 1:
         m.shard()
-    g = torch.Generator().manual_seed(1234)
-    views = {"img": torch.rand(1, n_total, 3, H, W, generator=g).to(dev)}
-    flags = [0, 0, 0]
-    if a.priors:  # SURVEY §8d synthetic priors: identity rotations, x = 0.1 i, fx = fy = W, principal point at the centre
-        pose = torch.eye(4).repeat(1, n_total, 1, 1)
-        pose[0, :, 0, 3] = 0.1 * torch.arange(n_total)
-        K = torch.zeros(1, n_total, 3, 3)
+    def make_views(nv, priors):
+        g = torch.Generator().manual_seed(1234)
+        vw = {"img": torch.rand(1, nv, 3, H, W, generator=g).to(dev)}
+        if not priors:
+            return vw, [0, 0, 0]
+        # SURVEY §8d synthetic priors: identity rotations, x = 0.1 i, fx = fy = W, principal point at the centre
+        pose = torch.eye(4).repeat(1, nv, 1, 1)
+        pose[0, :, 0, 3] = 0.1 * torch.arange(nv)
+        K = torch.zeros(1, nv, 3, 3)
         K[..., 0, 0] = W; K[..., 1, 1] = H; K[..., 0, 2] = W / 2; K[..., 1, 2] = H / 2; K[..., 2, 2] = 1
-        views["camera_pose"] = pose.to(dev)
-        views["camera_intrinsics"] = K.to(dev)
-        flags = [1, 0, 1]
+        vw["camera_pose"] = pose.to(dev)
+        vw["camera_intrinsics"] = K.to(dev)
+        return vw, [1, 0, 1]
+
+    views, flags = make_views(n_total, a.priors)
+    m.reserve(n_local, n_total, H, W)  # workspace + tables: the forward itself never allocates
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -165,13 +173,43 @@ def main():
     whole_ms, _ = m.profile_read(4)
     m.profile(False)
 
+    # North-star leg (N = 1 only, after and outside the timed region): BASELINE C3 = 32 views x 518 x 518, camera-pose +
+    # intrinsics priors, same weights; 1 warm-up + 3 timed steps + 1 HIP-event step for the cross-view attention class.
+    north = None
+    if world == 1 and not a.no_north_star and not a.tiny and not (n_local == 32 and a.priors):
+        v3, f3 = make_views(32, True)
+        m.reserve(32, 32, H, W)
+        m(v3, f3)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            m(v3, f3)
+        torch.cuda.synchronize(dev)
+        ms3 = (time.perf_counter() - t1) / 3 * 1e3
+        m.profile(True)
+        m(v3, f3)
+        torch.cuda.synchronize(dev)
+        ga_ms, ga_n = m.profile_read(0)
+        m.profile(False)
+        fl3 = flop_model(cfg, 32, 32, H, W)
+        north = {"config": "C3: 32-view 518x518 bf16, camera-pose + intrinsics priors, 1 GPU", "steps": 3, "ms_per_step": round(ms3, 3),
+                 "views_per_s": round(32 / (ms3 * 1e-3), 2), "whole_forward_tflops": round(fl3["total"] / (ms3 * 1e-3) / 1e12, 1),
+                 "global_attention": {"ms_total": round(ga_ms, 3), "launches": ga_n, "tflop_total": round(fl3["global_attention"] / 1e12, 2),
+                                      "tflops": round(fl3["global_attention"] / (ga_ms * 1e-3) / 1e12, 1),
+                                      "frac": round(fl3["global_attention"] / (ga_ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
+                                      "target_frac": 0.6}}
+        log(f"north-star leg: {ms3:.1f} ms/step, cross-view attention {north['global_attention']['tflops']} TF/s")
+        del v3
+
     if rank == 0:
         dom = max(classes, key=lambda k: classes[k]["ms_total"])
         ach = classes[dom]["tflops"]
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # value is the committed rocprofv3 --pmc measurement of THIS workload (profiles/r01_traffic_n1.json), else null
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_n1.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic_n1.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic_n1.json")
         if world == 1 and n_local == 8 and H == 518 and not a.tiny and os.path.exists(tpath):
             traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -186,10 +224,13 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                 "config": {"workload": f"{n_total}-view {H}x{W} {a.dtype}, {'camera-pose + intrinsics priors' if a.priors else 'no priors'}, camera+depth+pointmap+normal heads, "
                                        f"{n_local} views/GPU" + (", tiny arch" if a.tiny else ", full 1.23B-param arch"),
-                           "views_per_gpu": n_local, "global_views": n_total, "parallelism": f"view-shard x{world}"},
+                           "views_per_gpu": n_local, "global_views": n_total, "parallelism": f"view-shard x{world}",
+                           "collective": (f"RCCL all-gather of K|V per global layer, world {m._comm[1]}" if m._comm else "none (1 GPU)")},
                 "roofline": roof}
+        if north is not None:
+            line["north_star"] = north
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, H, W, 1)
+            line["cpu_baseline"] = cpu_baseline(cfg, H, W, a.cpu_views)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -47,10 +47,15 @@ __device__ __forceinline__ uint32_t pack2(float a, float b, int T) {
                         : __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 
-// smallest T-representable value >= x (x finite): used for the running max so that the value the MFMA
-// subtracts (carried as a 16-bit operand) is exactly m_run and scores never exceed it
+// smallest T-representable INTEGER >= x (x finite): used for the running max so that (a) the value the MFMA subtracts
+// (carried as a 16-bit operand) is exactly m_run and scores never exceed it, and (b) P = 2^(S - m_run) has the same
+// mantissa whatever m_run is: the 16-bit rounding of P — and with it the result up to fp32 summation order — does not
+// depend on the order the key tiles are visited in, on the lazy-max policy, on KV splits or on how keys are sharded
+// over ranks (a fractional max would re-round every P by half an ulp of the 16-bit type when it moves).
+// ceilf(x) is T-representable for |x| <= 256 (bf16) / 2048 (f16); beyond that every T value is an integer anyway.
 template <int T>
 __device__ __forceinline__ float ceil_t16(float x) {
+  x = ceilf(x);
   u16 u = f2t<T>(x);
   float y = t2f<T>(u);
   if (y < x) {

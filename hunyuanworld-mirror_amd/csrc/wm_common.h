@@ -19,7 +19,11 @@ __device__ __forceinline__ u16 f2bf(float x) {  // round-to-nearest-even, NaN pr
   return __builtin_bit_cast(u16, b);
 }
 __device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, ((uint32_t)v) << 16); }
+// fp32 -> f16 SATURATES at +-65504 (one v_med3_f32): the reference's DPT heads are fp32 (worldmirror.py:146) and an unbounded
+// ReLU / residual chain of a real checkpoint may exceed f16's range; an inf operand would turn a whole MFMA row into NaN.
+// A NaN input comes out as -65504 (v_med3 orders NaN low), i.e. it is not propagated.
 __device__ __forceinline__ u16 f2h(float x) {
+  x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
   _Float16 h = (_Float16)x;
   return __builtin_bit_cast(u16, h);
 }

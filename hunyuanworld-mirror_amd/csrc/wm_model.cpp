@@ -77,7 +77,9 @@ struct wm_handle {
   // workspace
   char* arena = nullptr;
   size_t arena_bytes = 0;
+  bool arena_owned = true;   // false: caller-provided (wm_set_workspace)
   int plan_n = -1, plan_nt = -1, plan_H = -1, plan_W = -1;
+  std::vector<std::string> missing;  // names wm_finalize_weights filled with their init values
   // shape-dependent device tables (allocated inside the arena by plan())
   std::map<std::string, void*> buf;
   // the DPT heads are mutually independent: each runs on its own stream (forked/joined with events)
@@ -451,7 +453,7 @@ extern "C" void wm_destroy(wm_handle* h) {
     if (kv.second.f32) (void)hipFree(kv.second.f32);
     if (kv.second.w16) (void)hipFree(kv.second.w16);
   }
-  if (h->arena) (void)hipFree(h->arena);
+  if (h->arena && h->arena_owned) (void)hipFree(h->arena);
   for (int i = 0; i < 4; ++i) {
     if (h->hstream[i]) (void)hipStreamDestroy(h->hstream[i]);
     if (h->hjoin[i]) (void)hipEventDestroy(h->hjoin[i]);
@@ -480,6 +482,7 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
   size_t numel = 1;
   for (auto s : sh) numel *= (size_t)s;
   Weight& w = h->w[n];
+  h->plan_n = -1;  // weight-derived workspace tables (resampled pos_embed, camera init token) are rebuilt by the next wm_reserve
   if (w.f32) { (void)hipFree(w.f32); w.f32 = nullptr; }
   if (w.w16) { (void)hipFree(w.w16); w.w16 = nullptr; }
   w.shape = sh;
@@ -525,24 +528,43 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
   return WM_OK;
 }
 
+// The value a parameter has in a freshly constructed reference model, where that value is deterministic: what a tensor
+// missing from the checkpoint keeps under load_state_dict(strict=False) (huggingface_hub mixin, worldmirror.py:13,16).
+// LayerNorm weight 1 / bias 0 (torch default); LayerScale gamma = init_values: 1.0 in the DINOv2 encoder
+// (visual_transformer.py:152-160), 0.01 in the multi-view blocks and the camera trunk (visual_transformer.py:65,
+// camera_head.py:24).  Everything else (Linear / conv weights and biases, learned tokens) is RANDOM in the reference
+// (trunc_normal / kaiming-uniform / normal(1e-6)): not reproducible, filled with 0 and reported through wm_missing_name.
+static float init_value_of(const std::string& n) {
+  const bool norm = n.find(".norm1.") != std::string::npos || n.find(".norm2.") != std::string::npos || n.find(".norm.") != std::string::npos ||
+                    n.find("q_norm.") != std::string::npos || n.find("k_norm.") != std::string::npos || n.find("token_norm.") != std::string::npos ||
+                    n.find("out_norm.") != std::string::npos;
+  if (norm) return ends_with(n, ".weight") ? 1.0f : 0.0f;
+  if (ends_with(n, ".gamma")) return n.find(".patch_embed.") != std::string::npos ? 1.0f : 0.01f;
+  return 0.0f;
+}
+
 extern "C" wm_status wm_finalize_weights(wm_handle* h, int* missing) {
   if (!h) return WM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  int miss = 0;
+  h->missing.clear();
   for (auto& kv : param_spec(h->cfg)) {
     auto it = h->w.find(kv.first);
     if (it != h->w.end() && it->second.set) continue;
-    ++miss;  // strict=False: a missing tensor stays zero
+    h->missing.push_back(kv.first);  // strict=False: a missing tensor keeps its init value (see init_value_of)
     size_t numel = 1;
     for (auto s : kv.second) numel *= (size_t)s;
-    std::vector<float> z(numel, 0.f);
+    std::vector<float> z(numel, init_value_of(kv.first));
     wm_status st = wm_set_weight(h, kv.first.c_str(), z.data(), kv.second.data(), (int)kv.second.size());
     if (st != WM_OK) return st;
     h->w[kv.first].set = false;
   }
-  if (missing) *missing = miss;
+  if (missing) *missing = (int)h->missing.size();
   h->finalized = true;
   return WM_OK;
+}
+
+extern "C" const char* wm_missing_name(const wm_handle* h, int i) {
+  return (h && i >= 0 && (size_t)i < h->missing.size()) ? h->missing[i].c_str() : nullptr;
 }
 
 // ====================================================================================== workspace
@@ -556,16 +578,21 @@ extern "C" size_t wm_workspace_bytes(const wm_handle* h, int n_local, int n_tota
 
 namespace {
 
-wm_status plan(wm_handle* h, const Dims& d, hipStream_t s) {
+// Builds the workspace for a shape: arena (library-owned unless the caller gave one), buffer map and the shape- /
+// weight-derived device tables.  Called by wm_reserve only — never from the forward pass.
+wm_status plan(wm_handle* h, const Dims& d) {
   if (h->plan_n == d.n && h->plan_nt == d.nt && h->plan_H == d.H && h->plan_W == d.W) return WM_OK;
   const wm_config& c = h->cfg;
   auto L = arena_layout(h, d);
   size_t tot = 0;
   for (auto& kv : L) tot += kv.second;
-  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipDeviceSynchronize());  // a forward of the previous shape may still be using the arena
   if (tot > h->arena_bytes) {
+    if (!h->arena_owned)
+      return fail(h, WM_ERR_STATE, "caller workspace too small: " + std::to_string(h->arena_bytes) + " < " + std::to_string(tot) + " bytes (wm_workspace_bytes)");
     if (h->arena) HIPCHK(h, hipFree(h->arena));
     h->arena = nullptr;
+    h->arena_bytes = 0;
     HIPCHK(h, hipMalloc((void**)&h->arena, tot));
     h->arena_bytes = tot;
   }
@@ -1025,8 +1052,10 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   HIPCHK(h, hipSetDevice(h->device));
   Ctx c{h, make_dims(h, n, nt, H, W_), s, cf.backbone_dtype, cf.head_dtype};
   const Dims& d = c.d;
-  wm_status st = plan(h, d, s);
-  if (st) return st;
+  // no allocation, no host-side table building and no synchronisation in the forward: the workspace must exist
+  if (!(h->plan_n == d.n && h->plan_nt == d.nt && h->plan_H == d.H && h->plan_W == d.W))
+    return fail(h, WM_ERR_STATE, "no workspace for this shape: call wm_reserve(h, n_local, n_total, H, W) first (and again after loading weights)");
+  wm_status st = WM_OK;
   for (int k = 0; k < 5; ++k) h->ev_used[k] = 0;
   ProfScope whole(h, 4, s);
   HIPCHK(h, hipMemsetAsync(B<char>(h, "ZERO256"), 0, 256, s));
@@ -1164,6 +1193,28 @@ extern "C" wm_status wm_forward_sharded(wm_handle* h, const float* img, int n_lo
                                         const float* pose7, const float* depth, const float* ray4, const int32_t cond_flags[3],
                                         const wm_outputs* out, void* stream) {
   return forward_impl(h, img, n_local, first_view, n_total, H, W, pose7, depth, ray4, cond_flags, out, (hipStream_t)stream);
+}
+
+extern "C" wm_status wm_set_workspace(wm_handle* h, void* device_ptr, size_t bytes) {
+  if (!h) return WM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  if (h->arena && h->arena_owned) HIPCHK(h, hipFree(h->arena));
+  h->arena = (char*)device_ptr;
+  h->arena_bytes = device_ptr ? bytes : 0;
+  h->arena_owned = device_ptr == nullptr;  // NULL hands the arena back to the library
+  h->plan_n = -1;
+  h->buf.clear();
+  return WM_OK;
+}
+
+extern "C" wm_status wm_reserve(wm_handle* h, int n_local, int n_total, int H, int W) {
+  if (!h) return WM_ERR_INVALID;
+  if (!h->finalized) return fail(h, WM_ERR_STATE, "weights not finalized");
+  if (n_local <= 0 || n_total < n_local || n_total % n_local) return fail(h, WM_ERR_INVALID, "n_total must be a positive multiple of n_local");
+  if (H <= 0 || W <= 0 || H % h->cfg.patch_size || W % h->cfg.patch_size) return fail(h, WM_ERR_INVALID, "H and W must be multiples of patch_size");
+  HIPCHK(h, hipSetDevice(h->device));
+  return plan(h, make_dims(h, n_local, n_total, H, W));
 }
 
 // ====================================================================================== communicator

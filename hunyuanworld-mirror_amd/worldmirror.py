@@ -163,6 +163,8 @@ class WorldMirror:
         self._handle = None
         self._device: Optional[torch.device] = None
         self._comm = None  # (rank, world)
+        self._reserved = None  # (n_local, n_total, H, W) the library workspace is laid out for
+        self._workspace = None  # caller-owned arena (use_workspace)
         self.training = False
         self.return_taps = False
         self.enable_prune = True  # GaussianSplatRenderer(enable_prune=True), worldmirror.py:113
@@ -181,7 +183,12 @@ class WorldMirror:
         with safe_open(os.path.join(path, "model.safetensors"), framework="pt", device="cpu") as f:  # "pt": bf16 / f16 checkpoints too
             for k in f.keys():
                 sd[k] = f.get_tensor(k)
-        m.load_state_dict(sd, strict=False)  # PyTorchModelHubMixin loads non-strictly: missing -> init value, unexpected -> ignored
+        missing, _ = m.load_state_dict(sd, strict=False)  # PyTorchModelHubMixin loads non-strictly: missing -> init value, unexpected -> ignored
+        if missing:
+            import warnings
+            warnings.warn(f"{len(missing)} parameter(s) missing from {path}/model.safetensors keep their init values "
+                          f"(LayerNorm 1/0, LayerScale 1.0 DINO / 0.01 elsewhere; randomly-initialised tensors of the reference become 0): "
+                          + ", ".join(missing[:8]) + (" ..." if len(missing) > 8 else ""))
         return m
 
     def load_state_dict(self, sd, strict: bool = False):
@@ -224,6 +231,8 @@ class WorldMirror:
         if L.wm_finalize_weights(self._handle, C.byref(miss)) != 0:
             raise RuntimeError(f"wm_finalize_weights: {self._err()}")
         self.missing_weights = miss.value
+        self.missing_weight_names = [L.wm_missing_name(self._handle, i).decode() for i in range(miss.value)]
+        self._reserved = None  # weight-derived workspace tables must be rebuilt
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def to(self, device):
@@ -243,8 +252,36 @@ class WorldMirror:
         if st != 0:
             raise RuntimeError(f"wm_create: {self._err()}")
         self._device = torch.device("cuda", idx)
+        self._reserved, self._workspace = None, None
         if self._host_weights:
             self._upload()
+        return self
+
+    def reserve(self, n_local: int, n_total: int, H: int, W: int):
+        """Prepare the workspace for a shape (wm_reserve): the forward itself never allocates.  forward() calls it on a
+        shape change; call it yourself to keep the first forward of a shape free of allocation too."""
+        key = (int(n_local), int(n_total), int(H), int(W))
+        if self._reserved != key:
+            if _lib.lib().wm_reserve(self._handle, *key) != 0:
+                raise RuntimeError(f"wm_reserve{key}: {self._err()}")
+            self._reserved = key
+        return self
+
+    def workspace_bytes(self, n_local: int, n_total: int, H: int, W: int) -> int:
+        return int(_lib.lib().wm_workspace_bytes(self._handle, n_local, n_total, H, W))
+
+    def use_workspace(self, buf: Optional[torch.Tensor]):
+        """Caller-owned arena (a uint8 device tensor, kept alive here); None returns ownership to the library."""
+        L = _lib.lib()
+        if buf is None:
+            st = L.wm_set_workspace(self._handle, None, 0)
+        else:
+            if buf.device != self._device or buf.dtype != torch.uint8 or not buf.is_contiguous():
+                raise ValueError("workspace must be a contiguous uint8 tensor on the model's device")
+            st = L.wm_set_workspace(self._handle, C.c_void_p(buf.data_ptr()), buf.numel())
+        if st != 0:
+            raise RuntimeError(f"wm_set_workspace: {self._err()}")
+        self._workspace, self._reserved = buf, None
         return self
 
     def cuda(self, device=None):
@@ -361,6 +398,7 @@ class WorldMirror:
             for i in range(4):
                 o.taps[i] = taps[i].data_ptr()
         fl = (C.c_int32 * 3)(*flags)
+        self.reserve(n, S, H, W)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if world == 1:
             st = L.wm_forward(self._handle, _lib.ptr(img_l), n, H, W, _lib.ptr(pose_l), _lib.ptr(depth_l), _lib.ptr(ray_l),

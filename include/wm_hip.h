@@ -70,14 +70,29 @@ void wm_destroy(wm_handle* h);
 const char* wm_last_error(const wm_handle* h);
 /* One reference state_dict tensor (fp32, host memory). Unknown names are ignored (strict=False). */
 wm_status wm_set_weight(wm_handle* h, const char* name, const float* host, const int64_t* shape, int ndim);
-/* Number of spec'd parameters still missing is written to *missing (strict=False: missing stay zero). */
+/* Number of spec'd parameters still missing is written to *missing.  strict=False semantics of the reference's loader
+ * (PyTorchModelHubMixin, src/models/models/worldmirror.py:13,16): a missing tensor keeps its init value where that
+ * value is deterministic — LayerNorm 1 / 0, LayerScale gamma 1.0 in the DINOv2 encoder and 0.01 elsewhere
+ * (visual_transformer.py:65,152-160; camera_head.py:24) — the rest (randomly initialised in the reference) is 0.
+ * wm_missing_name(h, i), i < *missing, lists them (NULL past the end). */
 wm_status wm_finalize_weights(wm_handle* h, int* missing);
+const char* wm_missing_name(const wm_handle* h, int i);
 /* DINO pos-embed resample for a non-native grid is done inside the library (host, once per shape);
  * exported for tests: in [gs*gs][D] -> out [gh*gw][D], bicubic antialias (vision_transformer.py:175-207). */
 void wm_host_resample_pos(const float* in, int gs, int D, int gh, int gw, float* out);
 
 /* ---- forward (replaces WorldMirror.forward, worldmirror.py:120-152) ---- */
 size_t wm_workspace_bytes(const wm_handle* h, int n_local, int n_total, int H, int W);
+/* Workspace ownership ("no hidden allocation in wm_forward").  wm_forward / wm_forward_sharded never allocate,
+ * synchronise or build tables: the workspace for the call's shape must have been prepared by wm_reserve, which sizes
+ * (wm_workspace_bytes) and lays out the arena and uploads the shape- and weight-derived tables (RoPE, resampled
+ * pos_embed of vision_transformer.py:175-207, the DPT UV tables of dense_head.py:253-263).  Call it again after a
+ * shape change or after wm_set_weight / wm_finalize_weights; a forward without it returns WM_ERR_STATE.
+ * The arena is the library's (hipMalloc inside wm_reserve, grown only when a shape needs more) unless the caller
+ * provides device memory with wm_set_workspace (NULL returns ownership to the library): then wm_reserve fails with
+ * WM_ERR_STATE instead of allocating when `bytes` < wm_workspace_bytes(...). */
+wm_status wm_reserve(wm_handle* h, int n_local, int n_total, int H, int W);
+wm_status wm_set_workspace(wm_handle* h, void* device_ptr, size_t bytes);
 /* img [N][3][H][W] f32 in [0,1]; priors already normalised as extract_priors returns them
  * (worldmirror.py:218-251): pose7 [N][7], depth [N][H][W], ray4 [N][4]; any may be NULL.
  * cond_flags = [pose, depth, rays]. */

@@ -121,17 +121,41 @@ def make_inputs(seed: int, S: int, H: int, W: int, priors: bool):
     return views
 
 
-def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="sensitive", splat_stride=1):
-    views_np = make_inputs(seed, S, H, W, priors=sum(flags) > 0)
+def make_inputs_518(seed: int, S: int, H: int, W: int, priors: bool):
+    """Benchmark-size inputs.  The image is NOT stored in the fixture (25 MB at 8 views): it is regenerated from the
+    seed exactly as bench.py draws it (torch.rand on a seeded CPU generator) and checked against a stored fp64 sum.
+    Priors (C3 flag set: camera pose + intrinsics) are small and stored."""
+    g = torch.Generator().manual_seed(seed)
+    views = {"img": torch.rand(1, S, 3, H, W, generator=g).numpy()}
+    if priors:
+        small = make_inputs(seed, S, 14, 14, True)
+        views["camera_pose"] = small["camera_pose"]
+        K = small["camera_intrinsics"] * np.float32(1.0)
+        K[..., 0, :] *= W / 14.0
+        K[..., 1, :] *= H / 14.0
+        views["camera_intrinsics"] = K.astype(np.float32)
+    return views
+
+
+def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="sensitive", splat_stride=1, regen_img=False):
+    if regen_img:
+        views_np = make_inputs_518(seed, S, H, W, priors=sum(flags) > 0)
+    else:
+        views_np = make_inputs(seed, S, H, W, priors=sum(flags) > 0)
     views = {k: torch.from_numpy(v.copy()) for k, v in views_np.items()}
-    store = {f"in_{k}": v for k, v in views_np.items()}
+    store = {f"in_{k}": v for k, v in views_np.items() if not (regen_img and k == "img")}
+    if regen_img:
+        store["regen_img"] = np.array(__import__("json").dumps({"kind": "torch_rand", "seed": seed, "shape": [1, S, 3, H, W]}))
+        store["sum_in_img"] = np.array(views_np["img"].astype(np.float64).sum())
     store["cond_flags"] = np.array(flags, np.int64)
     store["cfg_json"] = np.array(__import__("json").dumps(cfg.to_dict()))
     store["weights_preset"] = np.array(preset)
     with torch.no_grad():
         if sum(flags) > 0:
             pri = m.extract_priors(views)
-            store["prior_depths"], store["prior_rays"], store["prior_poses"] = [p.numpy() for p in pri]
+            for nm, pr_ in zip(("prior_depths", "prior_rays", "prior_poses"), pri):
+                if pr_ is not None:
+                    store[nm] = pr_.numpy()
             taps, psi = m.visual_geometry_transformer(views["img"], pri, cond_flags=flags)
         else:
             taps, psi = m.visual_geometry_transformer(views["img"])
@@ -182,6 +206,8 @@ def main():
     ap.add_argument("--refinit", action="store_true", help="goldens with the reference's own init statistics")
     ap.add_argument("--full-priors", action="store_true", help="full architecture, 2 x 224^2, pose + intrinsics priors (the C3 flag set)")
     ap.add_argument("--full-nonsquare", action="store_true", help="full architecture, 3 views of 154 x 210 (non-square: pos-embed resample), pose + depth + intrinsics priors")
+    ap.add_argument("--full-518", action="store_true", help="full architecture at the benchmarked size: BASELINE C2 inputs of bench.py (8 x 518^2, seed 1234, no priors) and 4 x 518^2 with pose + intrinsics priors, both presets for C2")
+    ap.add_argument("--cases", default="", help="comma-separated subset of the --full-518 cases")
     ap.add_argument("--full-gs", action="store_true", help="full architecture with the 3D-Gaussian head (BASELINE config 5 path, rasterisation not run), 2 x 224^2")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -194,6 +220,21 @@ def main():
         cfg = WMConfig()
         m = build_reference(cfg)
         run_case(m, cfg, "full_3v_154x210_allpriors", 14, 3, 154, 210, [1, 1, 1], sub=2, keep_taps=False)
+        return
+    if a.full_518:
+        cfg = WMConfig()
+        want = set(a.cases.split(",")) if a.cases else None
+        todo = [c for c in ("full_8v_518_noprior", "full_4v_518_pose_ray") if want is None or c in want]
+        if todo:
+            m = build_reference(cfg)
+            if "full_8v_518_noprior" in todo:
+                run_case(m, cfg, "full_8v_518_noprior", 1234, 8, 518, 518, [0, 0, 0], sub=8, keep_taps=False, regen_img=True)
+            if "full_4v_518_pose_ray" in todo:
+                run_case(m, cfg, "full_4v_518_pose_ray", 4321, 4, 518, 518, [1, 0, 1], sub=8, keep_taps=False, regen_img=True)
+            del m
+        if want is None or "refinit_full_8v_518_noprior" in want:
+            m = build_reference(cfg, "refinit")
+            run_case(m, cfg, "refinit_full_8v_518_noprior", 1234, 8, 518, 518, [0, 0, 0], sub=8, keep_taps=False, preset="refinit", regen_img=True)
         return
     if a.full_gs:
         cfg = WMConfig(enable_gs=True)

@@ -11,6 +11,16 @@ writes tests/golden/*.npz; tests/test_oracle_golden.py checks this file against 
 
 Every function cites the reference lines it restates (paths relative to the reference root).
 ``P`` is a dict name -> fp32 torch tensor using the reference's state_dict names.
+
+Rounding emulation (``forward(..., emulate=("bf16", "f16"))``): the same restatement, but every operand of a
+contraction that the HIP build feeds to a 16-bit MFMA is rounded to that type first, at exactly the build's rounding
+points (DESIGN.md "Numerics"): backbone = LayerNorm output, q / k / v after q-k-norm + RoPE + the folded softmax scale,
+the softmax numerator P (base 2, against an INTEGER running max, so the rounding does not depend on the order keys
+are visited in), the attention output, GELU(fc1), the patch matrix, all Linear weights; DPT heads = every conv / GEMM
+input activation and weight (fp32 activations in between, the refinenet 1x1 ``out_conv`` applied before the bilinear
+resize as the build does).  Accumulation, residual stream, LayerNorm, softmax sums, the camera head and the last 1x1
+conv of each head stay fp32.  What remains between the HIP build and this mode is fp32 summation order and the
+hardware exp2 / rcp — i.e. kernel error, separated from the recipe's rounding error.
 """
 from __future__ import annotations
 
@@ -21,6 +31,25 @@ import torch
 import torch.nn.functional as F
 
 Tensor = torch.Tensor
+
+LOG2E = 1.4426950408889634
+_EMU = None  # (backbone torch dtype, head torch dtype) while forward(..., emulate=...) runs, else None
+_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16}
+
+
+def _rb(x: Tensor) -> Tensor:
+    """round to the backbone's 16-bit operand type (emulation mode only)"""
+    return x if _EMU is None else x.to(_EMU[0]).float()
+
+
+def _rh(x: Tensor) -> Tensor:
+    """round to the DPT heads' 16-bit operand type (emulation mode only); f16 saturates at +-65504 as the build's staging does"""
+    if _EMU is None:
+        return x
+    if _EMU[1] == torch.float16:
+        x = x.clamp(-65504.0, 65504.0)
+    return x.to(_EMU[1]).float()
+
 
 RESNET_MEAN = (0.485, 0.456, 0.406)   # src/models/models/visual_transformer.py:16
 RESNET_STD = (0.229, 0.224, 0.225)    # :17
@@ -45,6 +74,11 @@ def gelu_erf(x: Tensor) -> Tensor:
 
 def linear(x: Tensor, P, name: str) -> Tensor:
     return x @ P[name + ".weight"].t() + P[name + ".bias"]
+
+
+def linear16(x: Tensor, P, name: str, r) -> Tensor:
+    """a Linear the build runs on 16-bit MFMA: operands through ``r`` (identity outside emulation), fp32 accumulate + bias"""
+    return r(x) @ r(P[name + ".weight"]).t() + P[name + ".bias"]
 
 
 def rope_tables(max_pos: int, dim: int, base: float) -> Tuple[Tensor, Tensor]:
@@ -75,13 +109,15 @@ def rope_2d(x: Tensor, pos: Tensor, base: float) -> Tensor:
 
 
 def attention(x: Tensor, P, p: str, heads: int, pos: Optional[Tensor], qk_norm: bool,
-              rope_base: float, kv_gather=None) -> Tensor:
+              rope_base: float, kv_gather=None, r=None) -> Tensor:
     """src/models/layers/attention.py:48-69 (softmax(q k^T / sqrt(hd)) v, no mask).
     kv_gather (view-sharded evaluation): maps this rank's K or V [B,H,L,hd] to the
     keys/values of ALL ranks concatenated on L; queries stay local."""
     B, L, C = x.shape
     hd = C // heads
-    qkv = linear(x, P, p + "qkv").reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    emu = _EMU is not None and r is not None  # r is None for the fp32 camera trunk
+    r = r if r is not None else (lambda t: t)
+    qkv = linear16(x, P, p + "qkv", r).reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     if qk_norm:  # attention.py:41-42,52 — LayerNorm(head_dim), eps 1e-5, affine
         q = layer_norm(q, P[p + "q_norm.weight"], P[p + "q_norm.bias"], 1e-5)
@@ -89,25 +125,34 @@ def attention(x: Tensor, P, p: str, heads: int, pos: Optional[Tensor], qk_norm: 
     if pos is not None:
         q = rope_2d(q, pos, rope_base)
         k = rope_2d(k, pos, rope_base)
+    scale = hd ** -0.5
+    if emu:  # the build folds scale * log2(e) into q before rounding it and runs the softmax in base 2
+        q, k, v = r(q * (scale * LOG2E)), r(k), r(v)
     if kv_gather is not None:
         k, v = kv_gather(k), kv_gather(v)
     o = torch.empty_like(q)
-    scale = hd ** -0.5
     step = 2048  # row blocks keep the score matrix small; result is identical
     for s in range(0, L, step):
-        a = (q[:, :, s:s + step] * scale) @ k.transpose(-1, -2)
-        o[:, :, s:s + step] = torch.softmax(a, -1) @ v
+        if emu:
+            a = q[:, :, s:s + step] @ k.transpose(-1, -2)
+            pm = torch.exp2(a - torch.ceil(a.max(-1, keepdim=True)[0]))   # integer max: P's rounding is order-independent
+            o[:, :, s:s + step] = (r(pm) @ v) / pm.sum(-1, keepdim=True)  # fp32 row sums of the un-rounded P
+        else:
+            a = (q[:, :, s:s + step] * scale) @ k.transpose(-1, -2)
+            o[:, :, s:s + step] = torch.softmax(a, -1) @ v
     o = o.transpose(1, 2).reshape(B, L, C)
-    return linear(o, P, p + "proj")
+    return linear16(o, P, p + "proj", r)
 
 
 def block(x: Tensor, P, p: str, heads: int, eps: float, pos=None, qk_norm=False,
-          rope_base: float = 100.0, kv_gather=None) -> Tensor:
-    """src/models/layers/block.py:72-93 eval branch; LayerScale layer_scale.py:16-17."""
+          rope_base: float = 100.0, kv_gather=None, r=None) -> Tensor:
+    """src/models/layers/block.py:72-93 eval branch; LayerScale layer_scale.py:16-17.
+    r: operand rounding of the 16-bit GEMMs / attention (emulation mode; None = fp32, e.g. the camera trunk)."""
+    rr = r if r is not None else (lambda t: t)
     h = layer_norm(x, P[p + "norm1.weight"], P[p + "norm1.bias"], eps)
-    x = x + attention(h, P, p + "attn.", heads, pos, qk_norm, rope_base, kv_gather) * P[p + "ls1.gamma"]
+    x = x + attention(h, P, p + "attn.", heads, pos, qk_norm, rope_base, kv_gather, r) * P[p + "ls1.gamma"]
     h = layer_norm(x, P[p + "norm2.weight"], P[p + "norm2.bias"], eps)
-    h = linear(gelu_erf(linear(h, P, p + "mlp.fc1")), P, p + "mlp.fc2")
+    h = linear16(gelu_erf(linear16(h, P, p + "mlp.fc1", rr)), P, p + "mlp.fc2", rr)
     return x + h * P[p + "ls2.gamma"]
 
 
@@ -135,13 +180,13 @@ def dino_encode(P, p: str, img: Tensor, cfg) -> Tensor:
     ps = cfg.patch_size
     assert H % ps == 0 and W % ps == 0  # patch_embed.py:67-68
     gh, gw = H // ps, W // ps
-    x = F.conv2d(img, P[p + "patch_embed.proj.weight"], P[p + "patch_embed.proj.bias"], stride=ps)
+    x = F.conv2d(_rb(img), _rb(P[p + "patch_embed.proj.weight"]), P[p + "patch_embed.proj.bias"], stride=ps)
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat([P[p + "cls_token"].expand(N, -1, -1), x], 1)
     x = x + dino_pos_embed(P, p, gh, gw)
     x = torch.cat([x[:, :1], P[p + "register_tokens"].expand(N, -1, -1), x[:, 1:]], 1)
     for i in range(cfg.dino_depth):
-        x = block(x, P, p + f"blocks.{i}.", cfg.dino_heads, 1e-6)
+        x = block(x, P, p + f"blocks.{i}.", cfg.dino_heads, 1e-6, r=_rb)
     x = layer_norm(x, P[p + "norm.weight"], P[p + "norm.bias"], 1e-6)
     return x[:, 1 + cfg.num_register_tokens:]
 
@@ -262,7 +307,7 @@ def backbone(P, img: Tensor, cfg, priors=None, cond_flags=(0, 0, 0),
         if cond_flags[1] == 1 and depths is not None:
             ps = cfg.patch_size
             d = F.pixel_unshuffle(depths.reshape(S, 1, H, W), ps).permute(0, 2, 3, 1)  # patch_embed.py:79-93
-            d = linear(gelu_erf(linear(d, P, v + "depth_embed.proj.2.fc1")), P, v + "depth_embed.proj.2.fc2")
+            d = linear16(gelu_erf(linear16(d, P, v + "depth_embed.proj.2.fc1", _rb)), P, v + "depth_embed.proj.2.fc2", _rb)
             patches = patches + d.reshape(S, gh * gw, D)
         if cond_flags[2] == 1 and rays is not None:
             h = F.silu(linear(rays.reshape(S, 4), P, v + "ray_embed.0"))
@@ -284,10 +329,10 @@ def backbone(P, img: Tensor, cfg, priors=None, cond_flags=(0, 0, 0),
     taps = []
     for i in range(cfg.depth):  # :309-339
         tok = block(tok.reshape(S, Pn, D), P, v + f"frame_blocks.{i}.", cfg.num_heads, 1e-5,
-                    pos_f, True, cfg.rope_freq)
+                    pos_f, True, cfg.rope_freq, r=_rb)
         frame_out = tok
         tok = block(tok.reshape(1, S * Pn, D), P, v + f"global_blocks.{i}.", cfg.num_heads, 1e-5,
-                    pos_g, True, cfg.rope_freq, kv_gather)
+                    pos_g, True, cfg.rope_freq, kv_gather, r=_rb)
         if i in cfg.intermediate_idxs:
             taps.append(torch.cat([frame_out.reshape(1, S, Pn, D), tok.reshape(1, S, Pn, D)], -1))
     return taps, psi
@@ -365,8 +410,8 @@ def uv_pos_embed(h: int, w: int, C: int, aspect: float) -> Tensor:
 def rcu(x: Tensor, P, p: str) -> Tensor:
     """dense_head.py:435-455 with nn.ReLU(inplace=True): the skip is relu(x)."""
     r = F.relu(x)
-    y = F.conv2d(r, P[p + "conv1.weight"], P[p + "conv1.bias"], padding=1)
-    y = F.conv2d(F.relu(y), P[p + "conv2.weight"], P[p + "conv2.bias"], padding=1)
+    y = F.conv2d(_rh(r), _rh(P[p + "conv1.weight"]), P[p + "conv1.bias"], padding=1)
+    y = F.conv2d(_rh(F.relu(y)), _rh(P[p + "conv2.weight"]), P[p + "conv2.bias"], padding=1)
     return y + r
 
 
@@ -377,6 +422,9 @@ def fusion(P, p: str, x: Tensor, skip: Optional[Tensor], size) -> Tensor:
     x = rcu(x, P, p + "resConfUnit2.")
     if size is None:
         size = (x.shape[-2] * 2, x.shape[-1] * 2)
+    if _EMU is not None:  # the build applies the 1x1 at the low resolution (both maps are linear, the weights sum to 1)
+        x = F.conv2d(_rh(x), _rh(P[p + "out_conv.weight"]), P[p + "out_conv.bias"])
+        return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=True)
     x = F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=True)
     return F.conv2d(x, P[p + "out_conv.weight"], P[p + "out_conv.bias"])
 
@@ -408,32 +456,32 @@ def dpt_head(P, p: str, taps: Sequence[Tensor], img: Tensor, psi: int, cfg, act:
         x = t[0, :, psi:]
         x = layer_norm(x, P[p + "norm.weight"], P[p + "norm.bias"], 1e-5)
         x = x.permute(0, 2, 1).reshape(S, -1, gh, gw)
-        x = F.conv2d(x, P[p + f"projects.{i}.weight"], P[p + f"projects.{i}.bias"])
+        x = F.conv2d(_rh(x), _rh(P[p + f"projects.{i}.weight"]), P[p + f"projects.{i}.bias"])
         x = x + 0.1 * uv_pos_embed(gh, gw, x.shape[1], aspect)
         if i == 0:
-            x = F.conv_transpose2d(x, P[p + "resize_layers.0.weight"], P[p + "resize_layers.0.bias"], stride=4)
+            x = F.conv_transpose2d(_rh(x), _rh(P[p + "resize_layers.0.weight"]), P[p + "resize_layers.0.bias"], stride=4)
         elif i == 1:
-            x = F.conv_transpose2d(x, P[p + "resize_layers.1.weight"], P[p + "resize_layers.1.bias"], stride=2)
+            x = F.conv_transpose2d(_rh(x), _rh(P[p + "resize_layers.1.weight"]), P[p + "resize_layers.1.bias"], stride=2)
         elif i == 3:
-            x = F.conv2d(x, P[p + "resize_layers.3.weight"], P[p + "resize_layers.3.bias"], stride=2, padding=1)
+            x = F.conv2d(_rh(x), _rh(P[p + "resize_layers.3.weight"]), P[p + "resize_layers.3.bias"], stride=2, padding=1)
         feats.append(x)
     s = p + "scratch."
-    rn = [F.conv2d(f, P[s + f"layer{i + 1}_rn.weight"], None, padding=1) for i, f in enumerate(feats)]
+    rn = [F.conv2d(_rh(f), _rh(P[s + f"layer{i + 1}_rn.weight"]), None, padding=1) for i, f in enumerate(feats)]
     o = fusion(P, s + "refinenet4.", rn[3], None, rn[2].shape[2:])
     o = fusion(P, s + "refinenet3.", o, rn[2], rn[1].shape[2:])
     o = fusion(P, s + "refinenet2.", o, rn[1], rn[0].shape[2:])
     o = fusion(P, s + "refinenet1.", o, rn[0], None)
-    o = F.conv2d(o, P[s + "output_conv1.weight"], P[s + "output_conv1.bias"], padding=1)
+    o = F.conv2d(_rh(o), _rh(P[s + "output_conv1.weight"]), P[s + "output_conv1.bias"], padding=1)
     o = F.interpolate(o, size=(gh * ps, gw * ps), mode="bilinear", align_corners=True)
     o = o + 0.1 * uv_pos_embed(o.shape[-2], o.shape[-1], o.shape[1], aspect)
     if collect is not None:
         collect[p + "fused"] = o
-    y = F.conv2d(o, P[s + "output_conv2.0.weight"], P[s + "output_conv2.0.bias"], padding=1)
+    y = F.conv2d(_rh(o), _rh(P[s + "output_conv2.0.weight"]), P[s + "output_conv2.0.bias"], padding=1)
     y = F.conv2d(F.relu(y), P[s + "output_conv2.2.weight"], P[s + "output_conv2.2.bias"])
     attr, conf = activate(y, act)
     attr, conf = attr[None], conf[None]
     if is_gs:  # dense_head.py:232-244
-        f = o + F.relu(F.conv2d(img[0], P[p + "input_merger.0.weight"], P[p + "input_merger.0.bias"], padding=3))
+        f = o + F.relu(F.conv2d(_rh(img[0]), _rh(P[p + "input_merger.0.weight"]), P[p + "input_merger.0.bias"], padding=3))
         return f[None], attr, conf
     return attr, conf
 
@@ -449,8 +497,8 @@ def gs_splats(P, gs_feat: Tensor, img: Tensor, cam_params: Tensor, gs_depth: Ten
     Returns the pre-prune splats (B=1): means [M,3], quats [M,4], scales [M,3], opacities [M],
     sh [M,1,3], weights [M]."""
     _, S, _, H, W = img.shape
-    x = F.conv2d(gs_feat[0], P["gs_renderer.gs_head.0.weight"], None, padding=1)
-    x = F.conv2d(F.relu(x), P["gs_renderer.gs_head.2.weight"], P["gs_renderer.gs_head.2.bias"])
+    x = F.conv2d(_rh(gs_feat[0]), _rh(P["gs_renderer.gs_head.0.weight"]), None, padding=1)
+    x = F.conv2d(_rh(F.relu(x)), _rh(P["gs_renderer.gs_head.2.weight"]), P["gs_renderer.gs_head.2.bias"])
     g = x.permute(0, 2, 3, 1).reshape(S * H * W, -1)
     quats, scales, opac, rsh, wts = torch.split(g, [4, 3, 1, 3, 1], -1)
     out = {}
@@ -510,8 +558,16 @@ HEAD_ACT = {"pts_head.": "inv_log", "depth_head.": "exp", "norm_head.": "norm", 
 
 
 def forward(P: Dict[str, Tensor], views: Dict[str, Tensor], cond_flags=(0, 0, 0), cfg=None,
-            collect: Optional[dict] = None, prune: bool = True) -> Dict[str, Tensor]:
-    """src/models/models/worldmirror.py:120-216."""
+            collect: Optional[dict] = None, prune: bool = True, emulate=None) -> Dict[str, Tensor]:
+    """src/models/models/worldmirror.py:120-216.
+    emulate = (backbone dtype, head dtype) as "bf16" / "f16": round where the HIP build rounds (module docstring)."""
+    global _EMU
+    if emulate is not None:
+        _EMU = (_DT[emulate[0]], _DT[emulate[1]])
+        try:
+            return forward(P, views, cond_flags, cfg, collect, prune, None)
+        finally:
+            _EMU = None
     img = views["img"].float()
     priors = extract_priors(views) if sum(cond_flags) > 0 else None
     taps, psi = backbone(P, img, cfg, priors, cond_flags, collect)

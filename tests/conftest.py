@@ -24,6 +24,14 @@ def load_golden(name):
     d["dpt_out_channels"] = tuple(d["dpt_out_channels"])
     cfg = WMConfig(**d)
     views = {k[3:]: v for k, v in z.items() if k.startswith("in_")}
+    if "regen_img" in z:  # benchmark-size fixtures: the image is drawn from its seed as bench.py draws it (oracle/gen_golden.py make_inputs_518)
+        import torch
+        g = json.loads(str(z["regen_img"]))
+        assert g["kind"] == "torch_rand"
+        gen = torch.Generator().manual_seed(int(g["seed"]))
+        img = torch.rand(*g["shape"], generator=gen).numpy()
+        assert abs(float(img.astype(np.float64).sum()) - float(z["sum_in_img"])) < 1e-6 * img.size, "regenerated image differs from the fixture's"
+        views["img"] = img
     outs = {k[4:]: v for k, v in z.items() if k.startswith("out_")}
     return cfg, views, [int(x) for x in z["cond_flags"]], outs, z
 
