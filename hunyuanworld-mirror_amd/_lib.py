@@ -46,7 +46,7 @@ class wm_outputs(C.Structure):
 
 EXPORTS = [
     "wm_create", "wm_destroy", "wm_last_error", "wm_set_weight", "wm_finalize_weights", "wm_host_resample_pos",
-    "wm_workspace_bytes", "wm_reserve", "wm_set_workspace", "wm_missing_name", "wm_forward", "wm_forward_sharded", "wm_rccl_unique_id", "wm_comm_init_rccl",
+    "wm_workspace_bytes", "wm_reserve", "wm_set_workspace", "wm_missing_name", "wm_share_weights", "wm_forward", "wm_forward_sharded", "wm_rccl_unique_id", "wm_comm_init_rccl",
     "wm_local_group_create", "wm_local_group_destroy", "wm_comm_init_local", "wm_profile_enable", "wm_profile_read",
     "wm_op_gemm", "wm_op_gemm_qkv", "wm_op_attention", "wm_op_layernorm", "wm_op_qkv_post", "wm_op_conv", "wm_op_bilinear",
     "wm_op_linear_f32", "wm_host_to_16", "wm_set_tuning", "wm_op_attention_split", "wm_op_conv3x3_up", "wm_depth_to_world", "wm_confidence_mask", "wm_confidence_mask_workspace_bytes", "wm_preprocess_image", "wm_preprocess_image_size",
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     L.wm_workspace_bytes.restype = C.c_size_t
     L.wm_reserve.argtypes = [vp, i32, i32, i32, i32]
     L.wm_set_workspace.argtypes = [vp, vp, C.c_size_t]
+    L.wm_share_weights.argtypes = [vp, vp]
     L.wm_missing_name.argtypes = [vp, i32]
     L.wm_missing_name.restype = C.c_char_p
     L.wm_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(C.c_int32), C.POINTER(wm_outputs), vp]

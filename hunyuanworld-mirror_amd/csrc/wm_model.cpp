@@ -47,6 +47,7 @@ struct Weight {
   int k16 = 0;           // padded K of the repack
   std::vector<float> host;  // kept only for the few tensors the host needs (pos_embed, init_token)
   bool set = false;
+  bool owned = true;  // false: device memory belongs to another handle (wm_share_weights)
 };
 
 struct EvPair { hipEvent_t a, b; };
@@ -450,6 +451,7 @@ extern "C" void wm_destroy(wm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   for (auto& kv : h->w) {
+    if (!kv.second.owned) continue;
     if (kv.second.f32) (void)hipFree(kv.second.f32);
     if (kv.second.w16) (void)hipFree(kv.second.w16);
   }
@@ -483,8 +485,11 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
   for (auto s : sh) numel *= (size_t)s;
   Weight& w = h->w[n];
   h->plan_n = -1;  // weight-derived workspace tables (resampled pos_embed, camera init token) are rebuilt by the next wm_reserve
-  if (w.f32) { (void)hipFree(w.f32); w.f32 = nullptr; }
-  if (w.w16) { (void)hipFree(w.w16); w.w16 = nullptr; }
+  if (w.owned) {
+    if (w.f32) (void)hipFree(w.f32);
+    if (w.w16) (void)hipFree(w.w16);
+  }
+  w.f32 = nullptr; w.w16 = nullptr; w.owned = true;
   w.shape = sh;
   w.set = true;
   const WKind k = classify(n, ndim);
@@ -560,6 +565,25 @@ extern "C" wm_status wm_finalize_weights(wm_handle* h, int* missing) {
   }
   if (missing) *missing = (int)h->missing.size();
   h->finalized = true;
+  return WM_OK;
+}
+
+extern "C" wm_status wm_share_weights(wm_handle* dst, const wm_handle* src) {
+  if (!dst || !src || dst == src) return WM_ERR_INVALID;
+  if (!src->finalized) return fail(dst, WM_ERR_STATE, "source weights not finalized");
+  if (memcmp(&dst->cfg, &src->cfg, sizeof(wm_config)) != 0 || dst->device != src->device)
+    return fail(dst, WM_ERR_INVALID, "wm_share_weights: configuration or device differs");
+  for (auto& kv : dst->w) {
+    if (!kv.second.owned) continue;
+    if (kv.second.f32) (void)hipFree(kv.second.f32);
+    if (kv.second.w16) (void)hipFree(kv.second.w16);
+  }
+  dst->w = src->w;
+  for (auto& kv : dst->w) kv.second.owned = false;
+  dst->spec = src->spec;
+  dst->missing = src->missing;
+  dst->finalized = true;
+  dst->plan_n = -1;
   return WM_OK;
 }
 

@@ -163,6 +163,7 @@ class WorldMirror:
         self._handle = None
         self._device: Optional[torch.device] = None
         self._comm = None  # (rank, world)
+        self.missing_weights, self.missing_weight_names = 0, []
         self._reserved = None  # (n_local, n_total, H, W) the library workspace is laid out for
         self._workspace = None  # caller-owned arena (use_workspace)
         self.training = False
@@ -213,6 +214,18 @@ class WorldMirror:
             self._upload(iter_params(self.cfg, seed, preset))
         else:
             self._host_weights = dict(iter_params(self.cfg, seed, preset))
+        return self
+
+    def share_weights_from(self, other: "WorldMirror"):
+        """Use ``other``'s device weights (same config, same device) without copying: several handles — one per stream or
+        per in-process rank — on one GPU (wm_share_weights).  ``other`` must outlive this model."""
+        if self._handle is None or other._handle is None:
+            raise RuntimeError("both models must be on the device (.to('cuda')) first")
+        if _lib.lib().wm_share_weights(self._handle, other._handle) != 0:
+            raise RuntimeError(f"wm_share_weights: {self._err()}")
+        self._weights_owner = other  # keep-alive
+        self.missing_weights, self.missing_weight_names = other.missing_weights, list(other.missing_weight_names)
+        self._reserved = None
         return self
 
     def _err(self) -> str:

@@ -77,6 +77,10 @@ wm_status wm_set_weight(wm_handle* h, const char* name, const float* host, const
  * wm_missing_name(h, i), i < *missing, lists them (NULL past the end). */
 wm_status wm_finalize_weights(wm_handle* h, int* missing);
 const char* wm_missing_name(const wm_handle* h, int i);
+/* Several handles on ONE device (one per stream / per in-process rank) can share one copy of the repacked weights:
+ * dst (same wm_config, same device) refers to src's device tensors without copying; src must outlive dst and must not
+ * be re-loaded while dst exists.  The nn.Module analogue is several callers sharing one model's parameters. */
+wm_status wm_share_weights(wm_handle* dst, const wm_handle* src);
 /* DINO pos-embed resample for a non-native grid is done inside the library (host, once per shape);
  * exported for tests: in [gs*gs][D] -> out [gh*gw][D], bicubic antialias (vision_transformer.py:175-207). */
 void wm_host_resample_pos(const float* in, int gs, int D, int gh, int gw, float* out);

@@ -53,6 +53,12 @@ def _sub(a, sub, H):
 
 def _check(name, got, emu, outs, sub, H, expect_north_star=None):
     rows = {}
+    if emu is None:  # no emulated output available (518-px fixture not generated yet): reference only, round-1 bounds
+        for k in ("pts3d", "depth", "normals", "camera_params"):
+            e = rel_l2(_sub(got[k], sub, H), outs[k])
+            print(f"  {name} {k}: GPU vs reference {e:.2e} (emulated output missing)")
+            assert e < (NORTH_STAR if expect_north_star and k != "camera_params" else 5e-3), (name, k, e)
+        return rows
     for k in KEYS:
         if k not in outs or k not in got:
             continue
@@ -110,7 +116,7 @@ def _emu_518(name, cfg, views, flags, preset, sub):
     path = os.path.join(GOLD, "emu_" + name + ".npz")
     if os.environ.get("WM_EMU_LIVE") or not os.path.exists(path):
         if not os.environ.get("WM_EMU_LIVE"):
-            pytest.skip(f"{path} missing (python oracle/gen_emulated.py)")
+            return None
         e = _emulated(cfg, views, flags, preset)
         return {k: _sub(v, sub, views["img"].shape[-2]) for k, v in e.items()}
     z = dict(np.load(path, allow_pickle=False))
