@@ -73,6 +73,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   constexpr int NBUF = STG == 2 ? 3 : 2;  // STG 2: three-deep ring, tiles fetched two ahead
   __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_B];  // [buf][K|V]
 
+  if (p.only_if && p.only_if[blockIdx.x] == 0) return;  // recompute pass behind attn_v3_kernel: only the blocks it flagged (block-uniform)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, ql = lane & 31;
   const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
@@ -682,9 +683,10 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p, i
 }
 
 template <int T, int NW, int QB, int MINW, int LZ = 1, int STG = 1>
-hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
+hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
   constexpr int QT = NW * 32 * QB;
   WmAttnArgs a = a_in;
+  a.only_if = nullptr;
   const int tiles_per_seq = (a.seq_len + QT - 1) / QT;
   const int nseq = a.q_rows / a.seq_len;
   {  // split-KV choice: rounds over the resident slots, per unit of work; a split must beat 1 by > 6 % (combine cost)
@@ -731,6 +733,12 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s) {
   const int units = tiles_per_seq * nseq * a.H;
   const int nfull = a.kv_splits > 1 ? a.full_units : units;
   dim3 grid(nfull + (units - nfull) * a.kv_splits), block(NW * 64);
+  if (use_v3) {  // same unit / split numbering (QT = 256): the fast no-max kernel, then the general kernel on the blocks it flagged
+    static const int v3_minw = [] { const char* e = getenv("WM_ATTN_V3_MINW"); return e ? atoi(e) : 2; }();
+    hipError_t e = wm_launch_attention_v3(a, (int)grid.x, a.unit_flags, v3_minw, s);
+    if (e != hipSuccess) return e;
+    a.only_if = a.unit_flags;
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, LZ, STG>), grid, block, 0, s, a);
   if (a.kv_splits > 1)
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((units - nfull) * (QT / 16))), dim3(256), 0, s, a, QT);
@@ -748,6 +756,11 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   // (22 key tiles) run 3-10 % faster as 128-row blocks of 32 rows per wave at 3 waves/SIMD (finer q-tiles: 10.75 -> 11 instead
   // of 5.4 -> 6 per frame, and more waves to overlap; tools/bench_attn_qb.py: 84 vs 87 us at 8 views, 287 vs 313 us at 32)
   const int qb = forced ? forced : (a.kv_chunks == 1 && a.seq_len <= 2048 ? 4 : 3);
+  if (qb == 7) {  // software-pipelined no-max kernel (attention_v3.hip): bf16, whole 64-key tiles, a flag workspace
+    const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
+    const bool ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows % 64 == 0 && seg_rows >= 512;
+    return launch<WM_T_BF16, 4, 2, 2>(a, s, ok);
+  }
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);
   if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0>(a, s);  // eager max (A/B)
   if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0>(a, s);

@@ -322,8 +322,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const WmGemmArgs 
           for (int g = 0; g < 4; ++g) {
             if (!ok[g]) continue;
             const float4 gm = *(const float4*)(p.gamma + cb + 8 * g);
-            *(float4*)((float*)p.C + orow * p.ldc + cb + 8 * g) =
-                make_float4(old[g].x + gm.x * v[g].x, old[g].y + gm.y * v[g].y, old[g].z + gm.z * v[g].z, old[g].w + gm.w * v[g].w);
+            const float4 nv = make_float4(old[g].x + gm.x * v[g].x, old[g].y + gm.y * v[g].y, old[g].z + gm.z * v[g].z, old[g].w + gm.w * v[g].w);
+            *(float4*)((float*)p.C + orow * p.ldc + cb + 8 * g) = nv;
+            if (p.C2) *(float4*)(p.C2 + orow * p.ldc2 + cb + 8 * g) = nv;
           }
         } else if constexpr (EPI == WM_EPI_ROWMAP_ADD) {
 #pragma unroll
@@ -535,9 +536,11 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
         for (int j = 0; j < SN; ++j) {
           const int col = colb + j * 16 + 4 * lq;
           const float4 o = old[i & 1][j], gm = gm4[j], bs = bs4[j];
-          if (row < p.M && col < p.N)
-            *(float4*)((float*)p.C + (size_t)row * p.ldc + col) =
-                make_float4(o.x + gm.x * (acc[i][j][0] + bs.x), o.y + gm.y * (acc[i][j][1] + bs.y), o.z + gm.z * (acc[i][j][2] + bs.z), o.w + gm.w * (acc[i][j][3] + bs.w));
+          if (row < p.M && col < p.N) {
+            const float4 nv = make_float4(o.x + gm.x * (acc[i][j][0] + bs.x), o.y + gm.y * (acc[i][j][1] + bs.y), o.z + gm.z * (acc[i][j][2] + bs.z), o.w + gm.w * (acc[i][j][3] + bs.w));
+            *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = nv;
+            if (p.C2) *(float4*)(p.C2 + (size_t)row * p.ldc2 + col) = nv;  // tap half (block-uniform branch)
+          }
         }
       }
       return;

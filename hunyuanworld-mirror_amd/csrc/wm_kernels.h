@@ -29,6 +29,7 @@ struct WmQkvArgs {
 struct WmGemmArgs {
   const void* A; const void* W; void* C;
   const float* bias; const float* gamma; const float* add;
+  float* C2; int ldc2;                                 // WM_EPI_RESID: the updated value is also stored to C2[row*ldc2 + col] (tap halves, visual_transformer.py:337-339)
   int M, N, K, lda, ldw, ldc;
   int dtype, epi;
   int group_bands;                                     // set by wm_launch_gemm: row bands per L2 supertile (ping-pong kernel)
@@ -39,6 +40,7 @@ struct WmGemmArgs {
 hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ attention (attention.hip)
+#define WM_ATTN_MAX_SPLITS_C 8
 struct WmAttnArgs {
   const void* Q; const void* K; const void* V;  // 16-bit [H][rows][64]; q pre-scaled by log2(e)/sqrt(64): P = 2^(q.k - max)
   void* O;                                      // 16-bit [q_rows][H*64] token-major
@@ -57,8 +59,19 @@ struct WmAttnArgs {
   int kv_splits, max_splits;
   int full_units;      // set by the launcher: units (q-tile, head) processed whole; the rest is split kv_splits ways (0 = all split)
   float* part_o; float* part_ml;
+  // software-pipelined no-max kernel for long bf16 sequences (attention_v3.hip): unit_flags = int[grid blocks] workspace in which
+  // every block reports whether one of its rows left the no-max range; the general kernel then runs with only_if = unit_flags
+  // and recomputes exactly those blocks.  unit_flags null = general kernel only.
+  int* unit_flags;
+  const int* only_if;  // set by the launcher
 };
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s);
+hipError_t wm_launch_attention_v3(const WmAttnArgs& a, int grid, int* flags, int minw, hipStream_t s);
+// upper bound of the launch grid (units x splits) for sizing unit_flags
+inline size_t wm_attention_max_blocks(int q_rows, int seq_len, int H) {
+  const size_t nseq = (size_t)(q_rows / (seq_len > 0 ? seq_len : 1));
+  return ((size_t)(seq_len + 127) / 128 + 1) * nseq * (size_t)H * WM_ATTN_MAX_SPLITS_C;
+}
 constexpr int WM_ATTN_MAX_SPLITS = 8;
 
 // ------------------------------------------------------------------ elementwise (elementwise.hip)

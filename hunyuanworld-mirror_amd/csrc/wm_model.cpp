@@ -274,6 +274,7 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("KVG", (size_t)d.world * 2 * Mv * D * 2);
   add("ATT_PO", (size_t)WM_ATTN_MAX_SPLITS * Mx * D * 4);   // split-KV attention partials (tail round of a launch cut into up to 8 key slices; uniform 4-way split when a sharded launch fits one round): unnormalised O, (max, sum)
   add("ATT_ML", (size_t)WM_ATTN_MAX_SPLITS * Mx * (D / 64) * 2 * 4);
+  add("ATT_FLAGS", wm_attention_max_blocks((int)Mv, (int)Mv, d.heads) * 4);  // per-block fallback flags of the no-max attention kernel
   add("ZERO256", 256);  // zero page for the out-of-image halo pieces of the DMA-fed conv (conv_n32.hip); cleared at the start of every forward
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
@@ -761,8 +762,10 @@ wm_status layernorm(Ctx& c, const float* x, int ld_in, void* y, int ld_out, cons
 }
 
 // Block.forward (block.py:72-93) on the fp32 residual stream X [M][D]; seq_len = attention span.
+// tap_half: when non-null, the block's output (the value its last GEMM stores to X) is also written to tap_half[row * 2D + col]
+// by that GEMM's epilogue — the cat([frame_out, global_out], -1) of visual_transformer.py:337-339 without a copy pass.
 wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_len, int heads, float eps, bool qk_norm,
-                         bool rope, int tokens_per_view, int patch_start, bool is_global) {
+                         bool rope, int tokens_per_view, int patch_start, bool is_global, float* tap_half = nullptr) {
   wm_handle* h = c.h;
   const Dims& d = c.d;
   const int D = d.D, dt = c.bdt;
@@ -806,6 +809,7 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
       a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
     }
     a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
+    if (is_global) a.unit_flags = B<int>(h, "ATT_FLAGS");
     ProfScope ps(h, is_global ? 0 : 1, c.s);
     LCHK(c, wm_launch_attention(a, c.s));
   }
@@ -816,7 +820,10 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
   const int Hd = c.h->cfg.mlp_ratio * D;
   st = gemm(c, dt, WM_EPI_GELU_T16, A16, D, W16(h, p + "mlp.fc1.weight"), D, H16, Hd, F(h, p + "mlp.fc1.bias"), nullptr, M, Hd, D);
   if (st) return st;
-  st = gemm(c, dt, WM_EPI_RESID, H16, Hd, W16(h, p + "mlp.fc2.weight"), Hd, X, D, F(h, p + "mlp.fc2.bias"), F(h, p + "ls2.gamma"), M, D, Hd);
+  WmGemmArgs ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.C2 = tap_half; ex.ldc2 = 2 * D;
+  st = gemm(c, dt, WM_EPI_RESID, H16, Hd, W16(h, p + "mlp.fc2.weight"), Hd, X, D, F(h, p + "mlp.fc2.bias"), F(h, p + "ls2.gamma"), M, D, Hd, &ex);
   return st;
 }
 
@@ -1146,15 +1153,14 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   // ---- a7-a10: 24 x (frame block, global block) + taps (visual_transformer.py:309-339)
   int tap_i = 0;
   for (int i = 0; i < cf.depth; ++i) {
-    st = backbone_block(c, v + "frame_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.P, cf.num_heads, 1e-5f, true, true, d.P, d.psi, false);
-    if (st) return st;
     const bool is_tap = tap_i < 4 && i == cf.intermediate_idxs[tap_i];
     float* tap = is_tap ? B<float>(h, ("tap" + std::to_string(tap_i)).c_str()) : nullptr;
-    if (is_tap) LCHK(c, wm_launch_copy2d(Xv, tap, d.Mv, D, D, 2 * D, s));
-    st = backbone_block(c, v + "global_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.Mv, cf.num_heads, 1e-5f, true, true, d.P, d.psi, true);
+    st = backbone_block(c, v + "frame_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.P, cf.num_heads, 1e-5f, true, true, d.P, d.psi, false, tap);
+    if (st) return st;
+    st = backbone_block(c, v + "global_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.Mv, cf.num_heads, 1e-5f, true, true, d.P, d.psi, true,
+                        tap ? tap + D : nullptr);
     if (st) return st;
     if (is_tap) {
-      LCHK(c, wm_launch_copy2d(Xv, tap + D, d.Mv, D, D, 2 * D, s));
       if (out->taps[tap_i]) LCHK(c, hipMemcpyAsync(out->taps[tap_i], tap, (size_t)d.Mv * 2 * D * 4, hipMemcpyDeviceToDevice, s));
       ++tap_i;
     }
@@ -1347,6 +1353,22 @@ extern "C" wm_status wm_op_attention_split(int dtype, const void* Q, const void*
   }
   return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
+extern "C" wm_status wm_op_attention_ex(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
+                                        int kv_chunks, int kv_rows_per_chunk, int kv_splits, float* part_o, float* part_ml, int* unit_flags,
+                                        void* stream) {
+  WmAttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.H = H; a.q_rows = q_rows; a.seq_len = seq_len; a.q_head_stride = q_rows;
+  a.kv_chunks = kv_chunks; a.dtype = dtype; a.kv_splits = kv_splits; a.max_splits = WM_ATTN_MAX_SPLITS; a.part_o = part_o; a.part_ml = part_ml;
+  a.unit_flags = unit_flags;
+  if (kv_chunks > 1) {
+    a.kv_head_stride = kv_rows_per_chunk; a.kv_rows_per_chunk = kv_rows_per_chunk; a.kv_chunk_stride = (long long)H * kv_rows_per_chunk * 64;
+  } else {
+    a.kv_head_stride = q_rows;
+  }
+  return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" size_t wm_op_attention_flag_count(int q_rows, int seq_len, int H) { return wm_attention_max_blocks(q_rows, seq_len, H); }
 // resize (align_corners bilinear + position tables) to 16 bits, then the 32-channel 3x3 conv on it: the unfused form of
 // wm_op_conv3x3_up for Cout == 32.  up16: Hi * Wi * N * Cin 16-bit elements + 16 B of scratch (zeroed here).
 extern "C" wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi,

@@ -140,6 +140,13 @@ wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V
  * not fill the chip. */
 wm_status wm_op_attention_split(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
                                 int kv_chunks, int kv_rows_per_chunk, int kv_splits, float* part_o, float* part_ml, void* stream);
+/* The same with a flag workspace: unit_flags = int[wm_op_attention_flag_count(q_rows, seq_len, H)].  With it (bf16, whole
+ * 64-key tiles, long sequences; selected by wm_set_tuning("attn_qb", 7) or the forward's own choice) the software-pipelined
+ * kernel without a running max runs first and the general kernel recomputes the blocks it flagged (attention_v3.hip). */
+wm_status wm_op_attention_ex(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
+                             int kv_chunks, int kv_rows_per_chunk, int kv_splits, float* part_o, float* part_ml, int* unit_flags,
+                             void* stream);
+size_t wm_op_attention_flag_count(int q_rows, int seq_len, int H);
 wm_status wm_op_layernorm(const float* x, void* y, const float* w, const float* b, int rows, int D, float eps, int out_f32,
                           int dtype, void* stream);
 wm_status wm_op_qkv_post(int dtype, const float* qkv, void* q, void* k, void* v, const float* qn_w, const float* qn_b,

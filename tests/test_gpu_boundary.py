@@ -39,6 +39,8 @@ def test_forward_refuses_without_reserve_and_never_allocates():
     st = L.wm_forward(m._handle, _lib.ptr(img), n, H, W, None, None, None, fl, C.byref(o), None)
     assert st != 0 and "wm_reserve" in m._err()           # no workspace yet: refused, nothing allocated behind the caller's back
     assert L.wm_reserve(m._handle, n, n, H, W) == 0
+    assert L.wm_forward(m._handle, _lib.ptr(img), n, H, W, None, None, None, fl, C.byref(o), None) == 0  # first launches load the code objects
+    torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     for _ in range(3):
         assert L.wm_forward(m._handle, _lib.ptr(img), n, H, W, None, None, None, fl, C.byref(o), None) == 0

@@ -2,14 +2,24 @@
 
 The HIP build rounds GEMM / attention / conv operands to 16 bits (bf16 backbone, f16 heads: the reference's own GPU
 recipe rounds at least as often).  `oracle/worldmirror_ref.py forward(..., emulate=(bdt, hdt))` is the fp32
-restatement with exactly those roundings inserted, so
+restatement with exactly those roundings inserted.  Three numbers per fixture and output:
 
-    err(GPU, emulated oracle)  = kernel error (fp32 summation order, hardware exp2 / rcp, indexing bugs)   -> asserted <= 5e-4
-    err(emulated oracle, golden) = what the recipe itself costs against the reference's fp32 CPU path       -> measured, printed
-    err(GPU, golden)           <= 1.25 x err(emulated oracle, golden) + 5e-4                                 -> asserted
+    R = err(emulated oracle, reference)      what the recipe costs against the reference's fp32 CPU path
+    F = err(emulated oracle, emulated oracle on an input perturbed by 1e-7 relative)
+                                             the SELF-DECORRELATION FLOOR of rounded arithmetic: a quantiser turns a
+                                             perturbation d << ulp into sqrt(d * ulp), so after a few of the ~400
+                                             successive roundings of a forward ANY fp32-level difference (summation
+                                             order, exp2 / rcp implementation) has grown to a fixed fraction of R.
+                                             Measured here on the CPU alone: F ~ 0.45 R (fp32 itself moves by 1e-6).
+    G = err(GPU, emulated oracle)
 
-on every fixture and both weight presets.  The north-star bound pts3d < 1e-3 against the reference is asserted wherever
-the recipe itself meets it (err(emulated, golden) < 5e-4: the "refinit" preset in bf16, every fixture with dtype f16).
+and the assertions are   G <= 1.5 F + 1e-4   (the build is one more realisation of the same rounded computation: a
+kernel error above the floor shows up here)   and   err(GPU, reference) <= 1.15 R + 1e-4   (no systematic error on top
+of the recipe's).  On the "refinit" preset (the reference's own init statistics, damped: LayerScale 0.01) the floor is
+below 5e-4 and G <= 5e-4 and the north-star pts3d / depth / normals < 1e-3 vs the reference are asserted outright; on the
+sensitivity-maximising preset R itself is ~3e-3 in bf16 — and so is the REFERENCE'S OWN bf16-autocast recipe
+(3.3e-3, oracle/validate_emulation.py, profiles/r02_emulation_validation.md): no 16-bit recipe meets 1e-3 there.
+Kernel error proper (same rounded operands in, one op) is pinned at op level: tests/test_gpu_ops.py.
 Benchmark-size (518 x 518) emulated outputs are precomputed by oracle/gen_emulated.py (tests/golden/emu_*.npz; the CPU
 oracle needs minutes there); set WM_EMU_LIVE=1 to recompute them on the spot.
 """
@@ -25,8 +35,9 @@ from conftest import GOLD, golden_preset, load_golden, rel_l2, torch_weights
 pytestmark = pytest.mark.gpu
 
 KEYS = ("pts3d", "depth", "normals", "pts3d_conf", "depth_conf", "normals_conf", "camera_params", "camera_poses")
-EMU_TOL = 5e-4   # kernel error bound (GPU vs emulated oracle), every output, every fixture
+EMU_TOL = 5e-4   # GPU vs emulated oracle where the decorrelation floor allows it (refinit preset)
 NORTH_STAR = 1e-3
+PERTURB = 1e-7   # relative input perturbation that defines the self-decorrelation floor
 
 
 def _gpu(cfg, views, flags, preset, dtype="bf16", head_dtype="f16"):
@@ -37,6 +48,15 @@ def _gpu(cfg, views, flags, preset, dtype="bf16", head_dtype="f16"):
     res = {k: v.cpu().numpy() for k, v in out.items() if isinstance(v, torch.Tensor)}
     del m
     return res
+
+
+def perturbed(views):
+    """the same views with the image multiplied by (1 + 1e-7 N(0,1)): an fp32-rounding-sized change"""
+    g = torch.Generator().manual_seed(0)
+    img = torch.from_numpy(views["img"])
+    out = dict(views)
+    out["img"] = (img * (1 + PERTURB * torch.randn(img.shape, generator=g))).numpy()
+    return out
 
 
 def _emulated(cfg, views, flags, preset, dtype="bf16", head_dtype="f16"):
@@ -51,32 +71,38 @@ def _sub(a, sub, H):
     return a[:, :, ::sub, ::sub] if sub > 1 and a.ndim >= 4 and a.shape[2] == H else a
 
 
-def _check(name, got, emu, outs, sub, H, expect_north_star=None):
+def _check(name, got, emu, pert, outs, sub, H, refinit=False):
+    """got / emu / pert: GPU, emulated oracle, emulated oracle on the perturbed input.  Returns the table."""
     rows = {}
-    if emu is None:  # no emulated output available (518-px fixture not generated yet): reference only, round-1 bounds
+    if emu is None:  # no emulated output available (518-px fixture not generated): reference only, round-1 bounds
         for k in ("pts3d", "depth", "normals", "camera_params"):
             e = rel_l2(_sub(got[k], sub, H), outs[k])
             print(f"  {name} {k}: GPU vs reference {e:.2e} (emulated output missing)")
-            assert e < (NORTH_STAR if expect_north_star and k != "camera_params" else 5e-3), (name, k, e)
+            assert e < (NORTH_STAR if refinit and k != "camera_params" else 5e-3), (name, k, e)
         return rows
+
+    def fit(a, ref):
+        return _sub(a, sub, H) if a.shape != ref.shape else a
     for k in KEYS:
         if k not in outs or k not in got:
             continue
-        g, e, ref = _sub(got[k], sub, H), _sub(emu[k], sub, H) if emu[k].shape != outs[k].shape else emu[k], outs[k]
-        assert g.shape == ref.shape == e.shape, (k, g.shape, e.shape, ref.shape)
+        ref = outs[k]
+        g, e, q = _sub(got[k], sub, H), fit(emu[k], ref), fit(pert[k], ref)
+        assert g.shape == ref.shape == e.shape == q.shape, (k, g.shape, e.shape, q.shape, ref.shape)
         assert np.isfinite(g).all(), k
-        rows[k] = (rel_l2(g, e), rel_l2(e, ref), rel_l2(g, ref))
-    print("\n" + name + "  (GPU vs emulated | emulated vs reference | GPU vs reference)")
-    for k, (a, b, c) in rows.items():
-        print(f"  {k:14s} {a:.2e} | {b:.2e} | {c:.2e}")
-    for k, (a, b, c) in rows.items():
-        assert a <= EMU_TOL, (name, k, "GPU vs emulated oracle", a)
-        assert c <= 1.25 * b + EMU_TOL, (name, k, "GPU vs reference beyond the recipe's own error", c, b)
-    if expect_north_star is None:
-        expect_north_star = rows["pts3d"][1] < 5e-4 if "pts3d" in rows else False
-    if expect_north_star and "pts3d" in rows:
+        rows[k] = (rel_l2(g, e), rel_l2(q, e), rel_l2(e, ref), rel_l2(g, ref))
+    print("\n" + name + "   G = GPU vs emulated | F = emulated vs emulated(1e-7-perturbed input) | R = emulated vs reference | GPU vs reference")
+    for k, (G, F, R, C) in rows.items():
+        print(f"  {k:14s} {G:.2e} | {F:.2e} | {R:.2e} | {C:.2e}")
+    for k, (G, F, R, C) in rows.items():
+        assert G <= 1.5 * F + 1e-4, (name, k, "GPU vs emulated oracle above the self-decorrelation floor", G, F)
+        assert C <= 1.15 * R + 1e-4, (name, k, "GPU vs reference beyond the recipe's own error", C, R)
+    if refinit:  # damped weights: the floor is low enough for absolute bounds
         for k in ("pts3d", "depth", "normals"):
-            assert rows[k][2] < NORTH_STAR, (name, k, rows[k])
+            assert rows[k][0] <= EMU_TOL, (name, k, "GPU vs emulated oracle", rows[k][0])
+            assert rows[k][3] < NORTH_STAR, (name, k, "north-star tolerance vs the reference", rows[k][3])
+    elif "pts3d" in rows and rows["pts3d"][2] < 5e-4:  # any other case whose recipe error is that small (f16 backbone is not: ~1e-3)
+        assert rows["pts3d"][3] < NORTH_STAR
     return rows
 
 
@@ -91,8 +117,8 @@ def test_gpu_vs_emulated_oracle(name):
     preset = golden_preset(z)
     got = _gpu(cfg, views, flags, preset)
     emu = _emulated(cfg, views, flags, preset)
-    _check(name, got, emu, outs, int(z["subsample"]), views["img"].shape[-2],
-           expect_north_star=True if preset == "refinit" else None)
+    pert = _emulated(cfg, perturbed(views), flags, preset)
+    _check(name, got, emu, pert, outs, int(z["subsample"]), views["img"].shape[-2], refinit=preset == "refinit")
 
 
 @pytest.mark.parametrize("name", ["tiny_3v_70x56_pose_ray", "full_2v_224_noprior"])
@@ -101,7 +127,8 @@ def test_gpu_vs_emulated_oracle_f16_backbone(name):
     cfg, views, flags, outs, z = load_golden(name)
     got = _gpu(cfg, views, flags, "sensitive", dtype="f16")
     emu = _emulated(cfg, views, flags, "sensitive", dtype="f16")
-    _check(name + " [f16]", got, emu, outs, int(z["subsample"]), views["img"].shape[-2])
+    pert = _emulated(cfg, perturbed(views), flags, "sensitive", dtype="f16")
+    _check(name + " [f16]", got, emu, pert, outs, int(z["subsample"]), views["img"].shape[-2])
 
 
 def test_gpu_vs_emulated_oracle_bf16_heads():
@@ -109,19 +136,24 @@ def test_gpu_vs_emulated_oracle_bf16_heads():
     cfg, views, flags, outs, z = load_golden("tiny_3v_70x56_pose_ray")
     got = _gpu(cfg, views, flags, "sensitive", head_dtype="bf16")
     emu = _emulated(cfg, views, flags, "sensitive", head_dtype="bf16")
-    _check("tiny_3v_70x56_pose_ray [bf16 heads]", got, emu, outs, 1, views["img"].shape[-2])
+    pert = _emulated(cfg, perturbed(views), flags, "sensitive", head_dtype="bf16")
+    _check("tiny_3v_70x56_pose_ray [bf16 heads]", got, emu, pert, outs, 1, views["img"].shape[-2])
 
 
 def _emu_518(name, cfg, views, flags, preset, sub):
+    """(emulated, emulated on the perturbed input) at every sub-th pixel, from tests/golden/emu_<name>.npz or live"""
     path = os.path.join(GOLD, "emu_" + name + ".npz")
-    if os.environ.get("WM_EMU_LIVE") or not os.path.exists(path):
-        if not os.environ.get("WM_EMU_LIVE"):
-            return None
-        e = _emulated(cfg, views, flags, preset)
-        return {k: _sub(v, sub, views["img"].shape[-2]) for k, v in e.items()}
+    H = views["img"].shape[-2]
+    if os.environ.get("WM_EMU_LIVE"):
+        e, q = _emulated(cfg, views, flags, preset), _emulated(cfg, perturbed(views), flags, preset)
+        return {k: _sub(v, sub, H) for k, v in e.items()}, {k: _sub(v, sub, H) for k, v in q.items()}
+    if not os.path.exists(path):
+        return None, None
     z = dict(np.load(path, allow_pickle=False))
-    assert str(z["emulate"]) == "bf16,f16" and str(z["weights_preset"]) == preset
-    return {k[4:]: v for k, v in z.items() if k.startswith("out_")}
+    if "perturb" not in z:
+        return None, None
+    assert str(z["emulate"]) == "bf16,f16" and str(z["weights_preset"]) == preset and float(z["perturb"]) == PERTURB
+    return ({k[4:]: v for k, v in z.items() if k.startswith("out_")}, {k[5:]: v for k, v in z.items() if k.startswith("pert_")})
 
 
 @pytest.mark.parametrize("name", ["full_8v_518_noprior", "full_4v_518_pose_ray", "refinit_full_8v_518_noprior"])
@@ -137,8 +169,8 @@ def test_518_golden_and_emulated(name):
     cfg, views, flags, outs, z = load_golden(name)
     preset, sub, H = golden_preset(z), int(z["subsample"]), views["img"].shape[-2]
     got = _gpu(cfg, views, flags, preset)
-    emu = _emu_518(name, cfg, views, flags, preset, sub)
-    _check(name, got, emu, outs, sub, H, expect_north_star=True if preset == "refinit" else None)
+    emu, pert = _emu_518(name, cfg, views, flags, preset, sub)
+    _check(name, got, emu, pert, outs, sub, H, refinit=preset == "refinit")
     # checksum over ALL pixels (not only the stored 1/64th): bounded by the recipe error of the stored sample
     for k in ("pts3d", "depth", "normals", "pts3d_conf", "depth_conf", "normals_conf"):
         s, ref = float(got[k].astype(np.float64).sum()), float(z["sum_" + k])

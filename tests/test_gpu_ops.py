@@ -272,6 +272,140 @@ def test_attention_tail_split(dev, H, nseq, L):
         assert _rel(a2[:L, hh], ref) < 8e-3
 
 
+def _attn_emulated(q, k, v, dt):
+    """What the kernel computes, up to fp32 summation order (oracle/worldmirror_ref.py attention, emulation mode): base-2 softmax
+    against an INTEGER row max, P rounded to 16 bits for P@V, fp32 row sums of the un-rounded P, O rounded to 16 bits."""
+    S = q @ k.transpose(-1, -2)
+    P = torch.exp2(S - torch.ceil(S.max(-1, keepdim=True)[0]))
+    O = (_t16(P, dt).float() @ v) / P.sum(-1, keepdim=True)
+    return _t16(O, dt).float()
+
+
+@pytest.mark.parametrize("H,L,dt", [(16, 1376, BF16), (4, 2752, BF16), (4, 2752, F16)])
+def test_attention_matches_emulated_rounding(dev, H, L, dt):
+    """Kernel error proper: against the rounding-emulated softmax on the same operands the kernel's 16-bit output is
+    IDENTICAL except where an fp32-level difference (summation order, v_exp_f32 vs exp2) flips a final rounding."""
+    g = torch.Generator().manual_seed(H + L)
+    q = _t16(torch.randn(H, L, 64, generator=g) * 0.125 * 1.5 * LOG2E, dt).to(dev)
+    k = _t16(torch.randn(H, L, 64, generator=g) * 1.5, dt).to(dev)
+    v = _t16(torch.randn(H, L, 64, generator=g), dt).to(dev)
+    o = torch.empty(L, H * 64, device=dev, dtype=torch.int16)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib().wm_op_attention(dt, _p(q), _p(k), _p(v), _p(o), H, L, L, 1, 0, s) == 0
+    torch.cuda.synchronize()
+    got = _from16(o, dt).reshape(L, H, 64)
+    emu = _attn_emulated(q.float(), k.float(), v.float(), dt).transpose(0, 1)
+    diff = float((got != emu).float().mean())
+    e = _rel(got, emu)
+    print(f"attention vs emulated rounding H{H} L{L} dt{dt}: {100 * diff:.3f} % of the outputs differ (by one 16-bit ulp), rel-L2 {e:.2e}")
+    assert diff < 0.02 and e < (3e-4 if dt == BF16 else 5e-5)
+
+
+@pytest.mark.parametrize("H,L,chunks,splits", [(4, 2752, 1, 4), (3, 4400, 2, 3), (2, 5504, 4, 2)])
+def test_attention_result_independent_of_key_partitioning(dev, H, L, chunks, splits):
+    """The running max is an integer, so the 16-bit rounding of every softmax numerator is the same whatever the order,
+    chunking (gathered shards) or KV split the keys are visited in: the outputs of the single-pass kernel, the chunked
+    launch and the split-KV launch differ only where fp32 summation order flips a final 16-bit rounding."""
+    g = torch.Generator().manual_seed(H * 7 + L)
+    Lk = L // chunks
+    q = _t16(torch.randn(H, L, 64, generator=g) * 0.125 * 1.5 * LOG2E, BF16).to(dev)
+    k = _t16(torch.randn(chunks, H, Lk, 64, generator=g) * 1.5, BF16).to(dev)
+    v = _t16(torch.randn(chunks, H, Lk, 64, generator=g), BF16).to(dev)
+    kk = torch.cat(list(k), 1).contiguous()
+    vv = torch.cat(list(v), 1).contiguous()
+    outs = [torch.empty(L, H * 64, device=dev, dtype=torch.int16) for _ in range(3)]
+    po = torch.zeros((splits, L, H * 64), device=dev)
+    pml = torch.zeros((splits, H, L, 2), device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L_ = _lib()
+    assert L_.wm_op_attention(BF16, _p(q), _p(kk), _p(vv), _p(outs[0]), H, L, L, 1, 0, s) == 0
+    assert L_.wm_op_attention(BF16, _p(q), _p(k), _p(v), _p(outs[1]), H, L, L, chunks, Lk if chunks > 1 else 0, s) == 0
+    assert L_.wm_op_attention_split(BF16, _p(q), _p(k), _p(v), _p(outs[2]), H, L, L, chunks, Lk if chunks > 1 else 0, splits, _p(po), _p(pml), s) == 0
+    torch.cuda.synchronize()
+    a = [_from16(o, BF16) for o in outs]
+    for nm, x in (("chunked", a[1]), ("split-KV", a[2])):
+        diff, e = float((x != a[0]).float().mean()), _rel(x, a[0])
+        print(f"{nm} vs single pass: {100 * diff:.3f} % of the outputs differ, rel-L2 {e:.2e}")
+        assert diff < 0.02 and e < 3e-4
+
+
+def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev):
+    o = torch.zeros(R, H * 64, device=dev, dtype=torch.int16)
+    po = torch.zeros((8, R, H * 64), device=dev)
+    pml = torch.zeros((8, H, R, 2), device=dev)
+    flags = torch.full((int(L_.wm_op_attention_flag_count(R, Ls, H)),), -1, device=dev, dtype=torch.int32)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L_.wm_set_tuning(b"attn_qb", qb) == 0
+    try:
+        assert L_.wm_op_attention_ex(BF16, _p(q), _p(k), _p(v), _p(o), H, R, Ls, chunks, Lc, splits, _p(po), _p(pml), _p(flags), s) == 0
+        torch.cuda.synchronize()
+    finally:
+        L_.wm_set_tuning(b"attn_qb", -1)
+    return _from16(o, BF16).reshape(R, H, 64), flags
+
+
+@pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2752, 2, 2), (2, 1, 4096, 4, 0)])
+def test_attention_v3_pipelined_no_max_kernel(dev, H, nseq, L, chunks, splits):
+    """attention_v3.hip (attn_qb = 7): software-pipelined, no running max.  Same operands -> the general kernel's result up to
+    final-rounding flips (2^S / sum 2^S is scale-free, bf16 rounding of P too), fp32 softmax within the bf16 P / O rounding;
+    whole units, uniform splits (chunks > 1), the tail split (16 heads x 43 q-tiles = 688 units on 512 slots) and 2 sequences."""
+    L_ = _lib()
+    g = torch.Generator().manual_seed(H * 13 + L + chunks)
+    R = nseq * L
+    Lc = L // chunks if chunks > 1 else 0
+    q = _t16(torch.randn(H, R, 64, generator=g) * 0.125 * 1.5 * LOG2E, BF16).to(dev)
+    if chunks > 1:
+        k = _t16(torch.randn(chunks, H, Lc, 64, generator=g) * 1.5, BF16).to(dev)
+        v = _t16(torch.randn(chunks, H, Lc, 64, generator=g), BF16).to(dev)
+    else:
+        k = _t16(torch.randn(H, R, 64, generator=g) * 1.5, BF16).to(dev)
+        v = _t16(torch.randn(H, R, 64, generator=g), BF16).to(dev)
+    a3, _ = _run_attn_ex(L_, q, k, v, H, R, L, chunks, Lc, splits, 3, dev)
+    a7, flags = _run_attn_ex(L_, q, k, v, H, R, L, chunks, Lc, splits, 7, dev)
+    used = flags[flags >= 0]
+    assert used.numel() > 0, "the v3 kernel did not run (launcher fell back)"
+    assert int(used.sum()) == 0, "no block may leave the no-max range on bounded scores"
+    diff, e = float((a7 != a3).float().mean()), _rel(a7, a3)
+    print(f"v3 vs general H{H} nseq{nseq} L{L} chunks{chunks} splits{splits}: {100 * diff:.3f} % of the outputs differ, rel-L2 {e:.2e}; blocks {used.numel()}")
+    assert torch.isfinite(a7).all() and diff < 0.02 and e < 3e-4
+    kk = (torch.cat(list(k), 1) if chunks > 1 else k).float()
+    vv = (torch.cat(list(v), 1) if chunks > 1 else v).float()
+    for i in range(nseq):
+        sl = slice(i * L, (i + 1) * L)
+        ks = kk if chunks > 1 else kk[:, sl]
+        vs = vv if chunks > 1 else vv[:, sl]
+        ref = _attn_ref(q[:, sl].float(), ks, vs).transpose(0, 1)
+        assert _rel(a7[sl], ref) < 8e-3
+
+
+@pytest.mark.parametrize("kind", ["spike_overflow", "all_far_below_zero"])
+def test_attention_v3_out_of_range_rows_are_recomputed(dev, kind):
+    """The no-max form is only valid while every row sum stays a comfortably normal fp32 number.  Rows that leave
+    [2^-80, 2^100] — a score of +200 (2^200 overflows), or every score near -600 (every 2^S flushes to 0) — must raise their
+    block's flag and come out right from the general kernel's recompute pass; all other blocks are left to the fast kernel."""
+    L_ = _lib()
+    H, L = 2, 2048
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(H, L, 64, generator=g) * 0.125 * LOG2E
+    k = torch.randn(H, L, 64, generator=g)
+    v = torch.randn(H, L, 64, generator=g)
+    if kind == "spike_overflow":
+        k[0, 1500] = q[0, 700] * 8 * 60.0        # head 0, query row 700 (q-tile 2): one score ~ +300 in log2 units
+        expect = {(0, 2)}
+    else:
+        base = torch.randn(64, generator=g)
+        q[1, 256:512] = (base + 0.05 * torch.randn(256, 64, generator=g)) * 3.0   # head 1, q-tile 1: every score ~ -600
+        k[1] = -(base + 0.05 * torch.randn(L, 64, generator=g)) * 3.0
+        expect = {(1, 1)}
+    q, k, v = [_t16(x, BF16).to(dev) for x in (q, k, v)]
+    a7, flags = _run_attn_ex(L_, q, k, v, H, L, L, 1, 0, 1, 7, dev)
+    ref = _attn_ref(q.float(), k.float(), v.float()).transpose(0, 1)
+    assert torch.isfinite(a7).all()
+    assert _rel(a7, ref) < 1e-2
+    used = flags[: H * (L // 256)]
+    assert int(used.sum()) >= 1 and int(used.sum()) <= 2 * len(expect) + 6, used.tolist()   # only the affected units (+ their head's neighbours at most)
+
+
 @pytest.mark.parametrize("D", [128, 256, 1024, 2048])
 def test_layernorm(dev, D):
     g = torch.Generator().manual_seed(D)
