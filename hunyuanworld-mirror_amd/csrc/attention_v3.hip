@@ -20,8 +20,13 @@
 // flag and the general kernel (running max, attention.hip) recomputes exactly the flagged units.  This removes the
 // max MFMAs (4 of 36 per tile), the max search and every data-dependent branch from the loop.
 //
-// K/V tiles stream by LDS-DMA into a 4-deep ring (tile t+2 is requested while tile t is consumed: two tile times of
-// flight), one barrier per tile, counted vmcnt.  f16 P would need the max (5-bit exponent): f16 stays on attention.hip.
+// Order inside a step: the 8 QK MFMAs first, then the 8 PV MFMAs — S of step s is complete half a step before SM(s)
+// reads it (no MFMA -> VALU result stall at a step's head), P of step s-1 a full step before PV reads it.  Fragments
+// are read from LDS one half-step ahead of their MFMAs: V^T of this step's PV behind the QK MFMAs, K of the next
+// step's QK behind the PV MFMAs.
+// K/V tiles stream by LDS-DMA into rings (K 4 deep, V 3 deep: V of tile t is consumed one tile after K of tile t);
+// at the barrier that opens tile t a wave requests K(t+3) and V(t+1): two tile times of flight for every piece, one
+// barrier per tile, counted vmcnt.  f16 P would need the max (5-bit exponent): f16 stays on attention.hip.
 #include "wm_common.h"
 #include "wm_kernels.h"
 
@@ -29,7 +34,7 @@ namespace {
 
 constexpr int KVB = 64;
 constexpr int TILE_B = KVB * 64 * 2;   // 8 KiB per K or V tile
-constexpr int NRING = 4;
+constexpr int KRING = 4, VRING = 3;
 constexpr int T = WM_T_BF16;
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
@@ -42,11 +47,12 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
-// One 1-KiB LDS-DMA piece (16 B per lane); M0 carries the LDS destination (saved / restored: M0 is reserved).
-__device__ __forceinline__ void dma16(const void* g, uint32_t lds_dst) {
+// One 1-KiB LDS-DMA piece (16 B per lane): source = wave-uniform base (SGPR pair) + per-lane byte offset (VGPR);
+// M0 carries the LDS destination (saved / restored: M0 is reserved).
+__device__ __forceinline__ void dma16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 // sched_group_barrier masks (LLVM SchedGroupMask)
@@ -58,7 +64,8 @@ __device__ __forceinline__ void dma16(const void* g, uint32_t lds_dst) {
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, int* __restrict__ flags) {
   constexpr int QB = 2, QT = 256;
-  __shared__ __attribute__((aligned(16))) char smem[NRING * 2 * TILE_B];  // [ring][K|V]
+  __shared__ __attribute__((aligned(16))) char smem[(KRING + VRING) * TILE_B];  // K ring | V ring
+  constexpr int VBASE = KRING * TILE_B;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, ql = lane & 31;
@@ -108,30 +115,42 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
   const int nt = t1 - t0;  // >= 2 (launcher)
 
-  // DMA: this wave moves pieces {2 wave, 2 wave + 1} of K and of V of every tile (source-side permutation builds the
-  // XOR-swizzled K rows and the [4 key][32 d] blocked V image, as in attention.hip)
-  int dma_c = t0 / ntpc, dma_j = t0 - dma_c * ntpc;  // (chunk, tile in chunk) of the next tile to request
-  const u16* gsrc[4];
-  int koff[2], voff[2];
+  // DMA: this wave moves pieces {2 wave, 2 wave + 1} of every K tile and of every V tile (source-side permutation builds the
+  // XOR-swizzled K rows and the [4 key][32 d] blocked V image, as in attention.hip).  Source = a wave-uniform tile pointer
+  // (advanced by one tile per request, by a chunk stride at a chunk's end: scalar arithmetic only) + fixed per-lane offsets.
+  // K and V run on separate counters: V lags K by two tiles.
+  uint32_t koff[2], voff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int pc = wave * 2 + i;
     const int kkey = pc * 8 + (lane >> 3), kd8 = (lane & 7) ^ ((kkey >> 1) & 7);
     const int off = pc * 1024 + lane * 16, blk = off >> 8;
     const int vkey = (blk >> 1) * 4 + ((off >> 6) & 3), vd8 = (blk & 1) * 4 + ((off >> 4) & 3);
-    koff[i] = kkey * 64 + kd8 * 8;
-    voff[i] = vkey * 64 + vd8 * 8;
+    koff[i] = (uint32_t)(kkey * 64 + kd8 * 8) * 2;
+    voff[i] = (uint32_t)(vkey * 64 + vd8 * 8) * 2;
   }
   const uint32_t smem_base = (uint32_t)(size_t)(lds_vp0)smem;
-  auto dma_begin = [&]() {  // source pointers of the next tile
-    const size_t base = (size_t)dma_c * p.kv_chunk_stride + (size_t)dma_j * KVB * 64;
-    gsrc[0] = Kb + base + koff[0]; gsrc[1] = Vb + base + voff[0];
-    gsrc[2] = Kb + base + koff[1]; gsrc[3] = Vb + base + voff[1];
-    if (++dma_j == ntpc) { dma_j = 0; ++dma_c; }
+  const long long chunk_jump = (p.kv_chunk_stride - (long long)ntpc * KVB * 64) * 2;  // bytes from a chunk's end to the next chunk's start
+  const int c0 = t0 / ntpc, j0 = t0 - c0 * ntpc;
+  const char* ksrc = (const char*)(Kb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);  // next K tile (wave-uniform)
+  const char* vsrc = (const char*)(Vb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);
+  int kj = j0, vj = j0;        // tile-in-chunk of the next K / V tile
+  int kslot = 0, vslot = 0;    // ring slots of those tiles
+  auto dma_k = [&]() {
+    const uint32_t dst = smem_base + kslot * TILE_B + wave * 2048;
+    dma16(ksrc, koff[0], dst);
+    dma16(ksrc, koff[1], dst + 1024);
+    ksrc += TILE_B;
+    if (++kj == ntpc) { kj = 0; ksrc += chunk_jump; }
+    kslot = kslot == KRING - 1 ? 0 : kslot + 1;
   };
-  auto dma_piece = [&](int buf, int i) {  // i: 0 K piece 0, 1 V piece 0, 2 K piece 1, 3 V piece 1
-    const int pc = wave * 2 + (i >> 1);
-    dma16(gsrc[i], smem_base + buf * 2 * TILE_B + (i & 1) * TILE_B + pc * 1024);
+  auto dma_v = [&]() {
+    const uint32_t dst = smem_base + VBASE + vslot * TILE_B + wave * 2048;
+    dma16(vsrc, voff[0], dst);
+    dma16(vsrc, voff[1], dst + 1024);
+    vsrc += TILE_B;
+    if (++vj == ntpc) { vj = 0; vsrc += chunk_jump; }
+    vslot = vslot == VRING - 1 ? 0 : vslot + 1;
   };
 
   f32x16 ot[QB][2];
@@ -147,38 +166,40 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
       for (int r = 0; r < 16; ++r) ot[b][d][r] = 0.f;
   }
 
-  // per-lane constant parts of the fragment addresses
-  const int vtr_lane = ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + h * 512;
-  int kaddr[2][4];  // [half][ks]: K row (32 hf + ql), 16-B chunk (2 ks + h) ^ swizzle(row)
+  // Fragment addresses (LDS byte addresses).  K: row (32 hf + ql), 16-B chunk (2 ks + h) ^ swizzle(row); the swizzle of row
+  // 32 + ql equals that of row ql, so half 1 = half 0 + 4096 (an immediate).  V^T: transposed 8-byte reads of the
+  // [4 key][32 d] blocked image.  The ring-slot part is added OUTSIDE the scheduled regions (lds_k / lds_v below), so a
+  // region holds exactly the instruction mix its sched_group_barrier pipeline names.
+  typedef const __attribute__((address_space(3))) s16x8* lds_frag_p;
+  uint32_t kaddr0[4];
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int key = hf * 32 + ql;
-      kaddr[hf][ks] = key * 128 + (((2 * ks + h) ^ ((key >> 1) & 7)) << 4);
-    }
+  for (int ks = 0; ks < 4; ++ks) kaddr0[ks] = smem_base + ql * 128 + (((2 * ks + h) ^ ((ql >> 1) & 7)) << 4);
+  const uint32_t vaddr0 = smem_base + VBASE + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 + h * 512;
 
   s16x8 kfr[4], vfr[2][2];
-  auto load_k = [&](int buf, int hf) {
-    const char* kt = smem + buf * 2 * TILE_B;
+  auto load_k = [&](const uint32_t (&ka)[4], int hf) {   // ka = kaddr0 + slot * TILE_B
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kfr[ks] = *(const s16x8*)(kt + kaddr[hf][ks]);
+    for (int ks = 0; ks < 4; ++ks) kfr[ks] = *(lds_frag_p)(uintptr_t)(ka[ks] + hf * 4096);
   };
-  auto load_v = [&](int buf, int hf) {
-    const char* vt = smem + buf * 2 * TILE_B + TILE_B;
+  auto load_v = [&](uint32_t va, int hf) {                // va = vaddr0 + slot * TILE_B
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        const char* b0 = vt + ((((hf * 8 + s2 * 4) * 2) + d) << 8) + vtr_lane;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(b0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(b0 + 2 * 2 * 256));
+        const uint32_t b0 = va + ((((hf * 8 + s2 * 4) * 2) + d) << 8);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(uintptr_t)(b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(uintptr_t)(b0 + 2 * 2 * 256));
         s16x8 vf;
         vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
         vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
         vfr[s2][d] = vf;
       }
   };
+  auto lds_k = [&](uint32_t (&ka)[4], int slot) {  // materialised here and now (the empty asm pins the values)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { ka[ks] = kaddr0[ks] + slot * TILE_B; asm volatile("" : "+v"(ka[ks])); }
+  };
+  auto lds_v = [&](int slot) { uint32_t va = vaddr0 + slot * TILE_B; asm volatile("" : "+v"(va)); return va; };
   auto qk = [&](int par) {  // S^T(half) = K(half) Q^T : st[par][b][r] = S[key 32 hf + (r&3) + 8(r>>2) + 4h][q = ql of block b]
     const f32x16 zero = {0};
 #pragma unroll
@@ -196,95 +217,111 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
 #pragma unroll
         for (int b = 0; b < QB; ++b) ot[b][d] = mfma32<T>(vfr[s2][d], pf[par][b][s2], ot[b][d]);
   };
-  auto sm = [&](int par) {  // P = 2^S, row sums (two chains per q-block), bf16 pack
+  auto sm_half = [&](int par, int b) {  // P = 2^S, row sums (two chains), bf16 pack — q-block b of one 32-key half
 #pragma unroll
-    for (int b = 0; b < QB; ++b)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float e[8];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        float e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          e[i] = __builtin_amdgcn_exp2f(st[par][b][8 * s2 + i]);
-          lsum[b][i & 1] += e[i];
-        }
-        uint4 u;
-        u.x = pack2bf(e[0], e[1]); u.y = pack2bf(e[2], e[3]); u.z = pack2bf(e[4], e[5]); u.w = pack2bf(e[6], e[7]);
-        pf[par][b][s2] = __builtin_bit_cast(s16x8, u);
+      for (int i = 0; i < 8; ++i) {
+        e[i] = __builtin_amdgcn_exp2f(st[par][b][8 * s2 + i]);
+        lsum[b][i & 1] += e[i];
       }
+      uint4 u;
+      u.x = pack2bf(e[0], e[1]); u.y = pack2bf(e[2], e[3]); u.z = pack2bf(e[4], e[5]); u.w = pack2bf(e[6], e[7]);
+      pf[par][b][s2] = __builtin_bit_cast(s16x8, u);
+    }
   };
-  // instruction order of a full step: per MFMA gap 2 exp + 3 plain VALU; K fragment reads of THIS step's QK in the
-  // first four gaps (behind the PV MFMAs), V fragment reads of the NEXT step's PV in the last eight gaps
-  auto pipeline_full = [&]() {
+  auto sm = [&](int par) { sm_half(par, 0); sm_half(par, 1); };
+  // A step is two scheduling regions of 8 MFMA gaps, each gap = 1 MFMA + (1 LDS read) + 2 exp + 3 plain VALU:
+  //   region A: QK MFMAs | the 8 V^T fragment reads of THIS step's PV | softmax of q-block 0
+  //   region B: PV MFMAs | the 4 K fragment reads of the NEXT step's QK | softmax of q-block 1
+  // (one kind of LDS read per region, so the scheduler cannot pull the next step's K reads in front of this step's V reads)
+  auto pipeline8 = [&](int nds) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 8; ++i) {
       __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-      if (i < 4 || i >= 8) __builtin_amdgcn_sched_group_barrier(SG_DSRD, 1, 0);
+      if (i < nds) __builtin_amdgcn_sched_group_barrier(SG_DSRD, 1, 0);
       __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
       __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
     }
   };
 
-  // ---- prologue: tiles t0, t0+1 requested; tile t0 landed
-  dma_begin();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dma_piece(0, i);
-  dma_begin();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dma_piece(1, i);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // ---- prologue: K(0), V(0), K(1), K(2) requested; all but K(2) landed
+  dma_k();
+  dma_v();
+  if (nt > 1) dma_k();
+  if (nt > 2) { dma_k(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-
-  // step 0: QK(0)            step 1: QK(1) + SM(0)
-  load_k(0, 0);
-  qk(0);
-  load_k(0, 1);
-  qk(1);
-  sm(0);
-  load_v(0, 0);   // for PV(0) in step 2
+  if (nt > 3) dma_k();   // K(3)
+  if (nt > 1) dma_v();   // V(1)
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- main loop over tiles 1 .. nt-1 (ring slot i & 3); tile i's body = steps 2i, 2i+1
-  //   step 2i  : PV(2i-2) [V half 0 of tile i-1, in registers]   QK(2i)   [K half 0 of tile i]   SM(2i-1)   loads V half 1 of tile i-1
-  //   step 2i+1: PV(2i-1) [V half 1 of tile i-1]                 QK(2i+1) [K half 1 of tile i]   SM(2i)     loads V half 0 of tile i
-  // barrier B_i before step 2i: everybody finished step 2i-1 => ring slot (i+2)&3 = (i-2)&3 is dead; own pieces of tile i landed
-  for (int i = 1; i < nt; ++i) {
-    const int buf = i & 3, pbuf = (i - 1) & 3;
-    const bool more = i + 2 < nt;
-    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile i+1's pieces were the youngest: everything landed
+  // tile 0: step 0 = QK(0); step 1 = QK(1) + SM(0)
+  uint32_t ka[4], kb[4];
+  lds_k(ka, 0);
+  lds_k(kb, 1);
+  load_k(ka, 0);
+  qk(0);
+  load_k(ka, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  qk(1);
+  sm(0);
+  load_k(kb, 0);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- tiles 1 .. nt-1.  Tile j (K ring slot j & 3; V(j-1) in V ring slot (j-1) % 3):
+  //   step 2j  : QK(2j)   [K half 0 of tile j, read in step 2j-1]   V^T reads of (tile j-1, half 0)   PV(2j-2)   SM(2j-1)   K reads of (tile j, half 1)
+  //   step 2j+1: QK(2j+1) [K half 1 of tile j]                      V^T reads of (tile j-1, half 1)   PV(2j-1)   SM(2j)     K reads of (tile j+1, half 0)
+  // barrier B_j opens step 2j: everybody finished step 2j-1, so K(j-1) and V(j-2) are dead = the slots K(j+3) and V(j+1) go to;
+  // the wait leaves only the four youngest pieces (K(j+2), V(j), requested at B_{j-1}) in flight: K(j+1), V(j-1) landed.
+  int vs = 0;  // V ring slot of tile j-1
+  for (int j = 1; j < nt; ++j) {
+    if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      dma_begin();
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dma_piece((i + 2) & 3, k);
-    }
+    if (j + 3 < nt) dma_k();
+    if (j + 1 < nt) dma_v();
+    lds_k(ka, j & 3);
+    lds_k(kb, (j + 1) & 3);
+    const uint32_t va = lds_v(vs);
     __builtin_amdgcn_sched_barrier(0);
-    // step 2i
-    load_k(buf, 0);
-    pv(0);
+    // step 2j
     qk(0);
-    sm(1);
-    load_v(pbuf, 1);
-    pipeline_full();
+    load_v(va, 0);
+    sm_half(1, 0);
+    pipeline8(8);
     __builtin_amdgcn_sched_barrier(0);
-    // step 2i+1
-    load_k(buf, 1);
-    pv(1);
+    pv(0);
+    load_k(ka, 1);
+    sm_half(1, 1);
+    pipeline8(4);
+    __builtin_amdgcn_sched_barrier(0);
+    // step 2j+1
     qk(1);
-    sm(0);
-    load_v(buf, 0);
-    pipeline_full();
+    load_v(va, 1);
+    sm_half(0, 0);
+    pipeline8(8);
     __builtin_amdgcn_sched_barrier(0);
+    pv(1);
+    load_k(kb, 0);   // past the last tile: a dead read of a valid slot (keeps the step branch-free)
+    sm_half(0, 1);
+    pipeline8(4);
+    __builtin_amdgcn_sched_barrier(0);
+    vs = vs == VRING - 1 ? 0 : vs + 1;
   }
-  // ---- epilogue: step 2nt: PV(2nt-2) + SM(2nt-1); step 2nt+1: PV(2nt-1)
+  // ---- epilogue: V(nt-1) landed (the last waits were vmcnt(0) + barrier for nt >= 2; nt == 1: the prologue's);
+  //      step 2nt: PV(2nt-2) + SM(2nt-1); step 2nt+1: PV(2nt-1)
+  if (nt == 1) vs = 0;
   {
-    const int lbuf = (nt - 1) & 3;
+    const uint32_t va = lds_v(vs);
+    load_v(va, 0);
     pv(0);
     sm(1);
-    load_v(lbuf, 1);
     __builtin_amdgcn_sched_barrier(0);
+    load_v(va, 1);
     pv(1);
   }
 
