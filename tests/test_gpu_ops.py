@@ -344,7 +344,7 @@ def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev):
     return _from16(o, BF16).reshape(R, H, 64), flags
 
 
-@pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2752, 2, 2), (2, 1, 4096, 4, 0)])
+@pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0)])
 def test_attention_v3_pipelined_no_max_kernel(dev, H, nseq, L, chunks, splits):
     """attention_v3.hip (attn_qb = 7): software-pipelined, no running max.  Same operands -> the general kernel's result up to
     final-rounding flips (2^S / sum 2^S is scale-free, bf16 rounding of P too), fp32 softmax within the bf16 P / O rounding;
