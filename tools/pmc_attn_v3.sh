@@ -7,10 +7,10 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export CASES=global_32v REPS=1 PYTHONPATH=$R
-rocprofv3 --kernel-trace --stats -d $R/$out/trace -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/trace.log 2>&1 || true
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d $R/$out/pmc1 -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/pmc1.log 2>&1 || true
-rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $R/$out/pmc2 -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/pmc2.log 2>&1 || true
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE -d $R/$out/pmc3 -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/pmc3.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/trace -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/trace.log 2>&1 || true
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $R/$out/pmc1 -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/pmc1.log 2>&1 || true
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $R/$out/pmc2 -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/pmc2.log 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/$out/pmc3 -- python3 $R/tools/bench_attn_v3.py 3 7 > $R/$out/pmc3.log 2>&1 || true
 cd $R
 python3 - <<PY
 import csv, glob, collections
