@@ -755,7 +755,9 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   // 64 rows per wave at 2 waves/SIMD with the lazy max for the long cross-view sequences; the short per-frame / DINO sequences
   // (22 key tiles) run 3-10 % faster as 128-row blocks of 32 rows per wave at 3 waves/SIMD (finer q-tiles: 10.75 -> 11 instead
   // of 5.4 -> 6 per frame, and more waves to overlap; tools/bench_attn_qb.py: 84 vs 87 us at 8 views, 287 vs 313 us at 32)
-  const int qb = forced ? forced : (a.kv_chunks == 1 && a.seq_len <= 2048 ? 4 : 3);
+  // long (cross-view) sequences: the software-pipelined no-max kernel (7) where it applies — bf16, whole 64-key tiles, a flag
+  // workspace — else the general kernel (3); tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views
+  const int qb = forced ? forced : (a.kv_chunks == 1 && a.seq_len <= 2048 ? 4 : 7);
   if (qb == 7) {  // software-pipelined no-max kernel (attention_v3.hip): bf16, whole 64-key tiles, a flag workspace
     const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
     const bool ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows % 64 == 0 && seg_rows >= 512;
