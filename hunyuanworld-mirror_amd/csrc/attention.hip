@@ -761,7 +761,7 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (qb == 7) {  // software-pipelined no-max kernel (attention_v3.hip): bf16, whole 64-key tiles, a flag workspace
     const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
     const bool ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows % 64 == 0 && seg_rows >= 512;
-    return launch<WM_T_BF16, 4, 2, 2>(a, s, ok);
+    return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s, ok) : launch<WM_T_F16, 4, 2, 2>(a, s, false);
   }
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);
   if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0>(a, s);  // eager max (A/B)
