@@ -317,19 +317,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
     __syncthreads();
   }
 
-  if (nsplit > 1) {  // unnormalised partial: O^T (fp32), running max and sum; the combine pass finishes the softmax
+  if (nsplit > 1 || p.force_partial) {  // unnormalised partial: O^T (fp32), running max and sum; the combine pass finishes the softmax
+    const int slot = p.part_slot0 + split;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
       const float lsum = xhalf_sum(l_run[b]);
       if (!q_valid[b]) continue;
       const size_t row = (size_t)(seq_row0 + qrow[b]);
-      float* op = p.part_o + ((size_t)split * p.q_rows + row) * (p.H * 64) + head * 64;
+      float* op = p.part_o + ((size_t)slot * p.q_rows + row) * (p.H * 64) + head * 64;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *(float4*)(op + 32 * d + 8 * g + 4 * h) = make_float4(ot[b][d][4 * g], ot[b][d][4 * g + 1], ot[b][d][4 * g + 2], ot[b][d][4 * g + 3]);
-      if (h == 0) *(float2*)(p.part_ml + (((size_t)split * p.H + head) * p.q_rows + row) * 2) = make_float2(m_run[b], lsum);
+      if (h == 0) *(float2*)(p.part_ml + (((size_t)slot * p.H + head) * p.q_rows + row) * 2) = make_float2(m_run[b], lsum);
     }
     return;
   }
@@ -705,6 +706,7 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
     // 2 (tools/bench_attn_split_chunks.py).  On one GPU (kv_chunks == 1) the combine pass costs what the better
     // balance gains (8 views: 940 vs 940 TF/s) and the short per-frame sequences lose 20 %.
     else if (a.kv_chunks > 1 && lim >= 2) best = lim < 4 ? lim : 4;
+    if (a.force_partial) best = a_in.kv_splits > 0 ? (a_in.kv_splits < lim ? a_in.kv_splits : lim) : 1;  // explicit uniform slices, no tail split
     a.kv_splits = best;
     a.full_units = 0;
     // Tail split: the launch's last, partly filled round — e.g. 688 units on 512 slots at 8 views: 176 whole blocks, one
@@ -717,7 +719,7 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
     // (tools/bench_attn_tail.py): 8 views 530 -> 480-495 us (+8-10 %), 16 views +8 %, 32 views +4-7 %; the short
     // per-frame sequences (22 key tiles) lose 10 % and are left alone (ntiles >= 64).
     const long tail = blocks % slots;
-    if (a_in.kv_splits == 0 && wm_tuning[WM_TUNE_ATTN_SPLITS] <= 0 && lim >= 2 && ntiles >= 64 && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
+    if (!a.force_partial && a_in.kv_splits == 0 && wm_tuning[WM_TUNE_ATTN_SPLITS] <= 0 && lim >= 2 && ntiles >= 64 && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
       auto round_cost = [&](long n) { const long rem = n % slots; return (double)(n / slots) + (rem == 0 ? 0.0 : rem * 2 <= slots ? 0.73 : 1.0); };
       double best_cost = round_cost(tail);
       int bs = 1;
@@ -740,12 +742,25 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
     a.only_if = a.unit_flags;
   }
   hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, LZ, STG>), grid, block, 0, s, a);
-  if (a.kv_splits > 1)
+  if (a.kv_splits > 1 && !a.force_partial)
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((units - nfull) * (QT / 16))), dim3(256), 0, s, a, QT);
   return hipGetLastError();
 }
 
 }  // namespace
+
+hipError_t wm_launch_attention_combine(const WmAttnArgs& a_in, int slots, hipStream_t s) {
+  if (a_in.q_rows <= 0) return hipSuccess;
+  if (slots < 1 || slots > WM_ATTN_MAX_SPLITS || !a_in.part_o || !a_in.part_ml) return hipErrorInvalidValue;
+  constexpr int QT = 256;  // only the row -> (unit, block) arithmetic of the combine kernel depends on it
+  WmAttnArgs a = a_in;
+  a.kv_splits = slots;
+  a.full_units = 0;
+  const int units = ((a.seq_len + QT - 1) / QT) * (a.q_rows / a.seq_len) * a.H;
+  if (a.dtype == WM_T_BF16) hipLaunchKernelGGL((attn_combine_kernel<WM_T_BF16>), dim3((unsigned)(units * (QT / 16))), dim3(256), 0, s, a, QT);
+  else hipLaunchKernelGGL((attn_combine_kernel<WM_T_F16>), dim3((unsigned)(units * (QT / 16))), dim3(256), 0, s, a, QT);
+  return hipGetLastError();
+}
 
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (a.q_rows <= 0) return hipSuccess;
@@ -758,6 +773,7 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   // long (cross-view) sequences: the software-pipelined no-max kernel (7) where it applies — bf16, whole 64-key tiles, a flag
   // workspace — else the general kernel (3); tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views
   const int qb = forced ? forced : (a.kv_chunks == 1 && a.seq_len <= 2048 ? 4 : 7);
+  if (a.force_partial && qb != 7 && qb != 3) return hipErrorInvalidValue;  // piecewise launches share the 256-row unit numbering
   if (qb == 7) {  // software-pipelined no-max kernel (attention_v3.hip): bf16, whole 64-key tiles, a flag workspace
     const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
     const bool ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows % 64 == 0 && seg_rows >= 512;

@@ -339,18 +339,19 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   __syncthreads();
   if (tid == 0) flags[blockIdx.x] = bad_sh[0] | bad_sh[1] | bad_sh[2] | bad_sh[3];
 
-  if (nsplit > 1) {  // unnormalised partial (running max 0): the combine pass finishes the softmax
+  if (nsplit > 1 || p.force_partial) {  // unnormalised partial (running max 0): the combine pass finishes the softmax
+    const int slot = p.part_slot0 + split;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
       if (!q_valid[b]) continue;
       const size_t row = (size_t)(seq_row0 + qrow[b]);
-      float* op = p.part_o + ((size_t)split * p.q_rows + row) * (p.H * 64) + head * 64;
+      float* op = p.part_o + ((size_t)slot * p.q_rows + row) * (p.H * 64) + head * 64;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *(float4*)(op + 32 * d + 8 * g + 4 * h) = make_float4(ot[b][d][4 * g], ot[b][d][4 * g + 1], ot[b][d][4 * g + 2], ot[b][d][4 * g + 3]);
-      if (h == 0) *(float2*)(p.part_ml + (((size_t)split * p.H + head) * p.q_rows + row) * 2) = make_float2(0.f, l[b]);
+      if (h == 0) *(float2*)(p.part_ml + (((size_t)slot * p.H + head) * p.q_rows + row) * 2) = make_float2(0.f, l[b]);
     }
     return;
   }

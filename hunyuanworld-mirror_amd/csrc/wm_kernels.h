@@ -64,7 +64,13 @@ struct WmAttnArgs {
   // and recomputes exactly those blocks.  unit_flags null = general kernel only.
   int* unit_flags;
   const int* only_if;  // set by the launcher
+  // Key range processed piecewise (sharded forward with the K/V all-gather overlapped, wm_model.cpp): with force_partial every
+  // unit — split or not — writes an unnormalised partial into slot part_slot0 + split (kv_splits = the explicit, uniform slice
+  // count of THIS launch, >= 1), nothing is combined; wm_launch_attention_combine then finishes all units over all slots.
+  int force_partial, part_slot0;
 };
+// finishes every unit (q_rows x H) over `slots` partial slots written by force_partial launches; O 16-bit [q_rows][H*64]
+hipError_t wm_launch_attention_combine(const WmAttnArgs& a, int slots, hipStream_t s);
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s);
 hipError_t wm_launch_attention_v3(const WmAttnArgs& a, int grid, int* flags, int minw, hipStream_t s);
 // upper bound of the launch grid (units x splits) for sizing unit_flags

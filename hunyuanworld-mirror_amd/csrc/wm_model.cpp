@@ -86,6 +86,9 @@ struct wm_handle {
   // the DPT heads are mutually independent: each runs on its own stream (forked/joined with events)
   hipStream_t hstream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t hfork = nullptr, hjoin[4] = {nullptr, nullptr, nullptr, nullptr};
+  // K/V all-gather of the sharded forward runs on its own queue, under the attention over the local keys
+  hipStream_t cstream = nullptr;
+  hipEvent_t cfork = nullptr, cjoin = nullptr;
   // profiling
   bool prof = false;
   std::vector<EvPair> ev[5];
@@ -462,6 +465,9 @@ extern "C" void wm_destroy(wm_handle* h) {
     if (h->hjoin[i]) (void)hipEventDestroy(h->hjoin[i]);
   }
   if (h->hfork) (void)hipEventDestroy(h->hfork);
+  if (h->cstream) (void)hipStreamDestroy(h->cstream);
+  if (h->cfork) (void)hipEventDestroy(h->cfork);
+  if (h->cjoin) (void)hipEventDestroy(h->cjoin);
   for (int k = 0; k < 5; ++k)
     for (auto& e : h->ev[k]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (h->comm.kind == 1 && h->comm.nccl) ncclCommDestroy(h->comm.nccl);
@@ -798,20 +804,79 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     memset(&a, 0, sizeof(a));
     a.Q = Q16; a.O = O16; a.H = heads; a.q_rows = M; a.q_head_stride = M; a.dtype = dt;
     static const bool force_gather = getenv("WM_FORCE_GATHER") != nullptr;  // 1-rank test of the collective path
-    if (is_global && (d.world > 1 || (force_gather && h->comm.kind != 0))) {
-      // K and V are adjacent: one all-gather of [K|V] per layer -> [world][2][H][M][64]
-      char* KVG = B<char>(h, "KVG");
-      st = comm_allgather(h, K16, KVG, 2 * hsz, c.s);
-      if (st) return st;
-      a.K = KVG; a.V = KVG + hsz; a.seq_len = M; a.kv_head_stride = M; a.kv_chunks = d.world;
-      a.kv_chunk_stride = (long long)(2 * hsz / 2); a.kv_rows_per_chunk = M;
-    } else {
-      a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
-    }
+    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return e ? atoi(e) != 0 : true; }();
     a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
     if (is_global) a.unit_flags = B<int>(h, "ATT_FLAGS");
-    ProfScope ps(h, is_global ? 0 : 1, c.s);
-    LCHK(c, wm_launch_attention(a, c.s));
+    const bool sharded = is_global && (d.world > 1 || (force_gather && h->comm.kind != 0));
+    const int ntpc = (M + 63) / 64;  // key tiles per rank chunk
+    if (sharded && overlap_env && d.world > 1 && ntpc >= 16) {
+      // ---- K/V all-gather UNDER the attention over this rank's own keys: the collective runs on the handle's
+      // communication queue as soon as the QKV epilogue has written K|V; the compute queue meanwhile attends the local chunk
+      // (1 / world of the keys: about the gather's own duration at 8 ranks), then the remote chunks — the gathered buffer's
+      // ranges [0, rank) and (rank, world) — and one combine pass over all partial slots.  Softmax partials make the order
+      // of the three key ranges irrelevant (attention.hip attn_combine_kernel).
+      if (!h->cstream) {
+        LCHK(c, hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+        LCHK(c, hipEventCreateWithFlags(&h->cfork, hipEventDisableTiming));
+        LCHK(c, hipEventCreateWithFlags(&h->cjoin, hipEventDisableTiming));
+      }
+      char* KVG = B<char>(h, "KVG");
+      const int rank = h->comm.rank, world = d.world;
+      LCHK(c, hipEventRecord(h->cfork, c.s));
+      // slice counts: minimise rounds x tiles per block over the 2-blocks-per-CU slots, per launch (uniform slices only)
+      static const int ncu = [] { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
+      const long slots = 2L * ncu, units = (long)((M + 255) / 256) * heads;
+      auto pick = [&](int ntiles, int smax) {
+        int best = 1; long best_cost = -1;
+        for (int S = 1; S <= smax && S * 8 <= ntiles; ++S) {
+          const long cost = ((units * S + slots - 1) / slots) * ((ntiles + S - 1) / S) + 6L * S;  // + partial write / read per slice
+          if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
+        }
+        return best;
+      };
+      const int nb = rank, nc = world - 1 - rank;  // remote chunks before / after the own one
+      const int sa = pick(ntpc, 2);
+      const int sb = nb > 0 ? pick(nb * ntpc, nc > 0 ? 3 : 6) : 0, sc = nc > 0 ? pick(nc * ntpc, WM_ATTN_MAX_SPLITS - sa - sb) : 0;
+      a.force_partial = 1;
+      // (1) local keys, while the gather is in flight
+      a.K = K16; a.V = V16; a.seq_len = M; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
+      a.kv_splits = sa; a.part_slot0 = 0;
+      {
+        ProfScope ps(h, 0, c.s);
+        LCHK(c, wm_launch_attention(a, c.s));
+      }
+      LCHK(c, hipStreamWaitEvent(h->cstream, h->cfork, 0));
+      st = comm_allgather(h, K16, KVG, 2 * hsz, h->cstream);
+      if (st) return st;
+      LCHK(c, hipEventRecord(h->cjoin, h->cstream));
+      LCHK(c, hipStreamWaitEvent(c.s, h->cjoin, 0));
+      // (2) remote keys: gathered chunks [0, rank) and (rank, world)
+      ProfScope ps(h, 0, c.s);
+      a.seq_len = M; a.kv_head_stride = M; a.kv_chunk_stride = (long long)(2 * hsz / 2); a.kv_rows_per_chunk = M;
+      if (nb > 0) {
+        a.K = KVG; a.V = KVG + hsz; a.kv_chunks = nb; a.kv_splits = sb; a.part_slot0 = sa;
+        LCHK(c, wm_launch_attention(a, c.s));
+      }
+      if (nc > 0) {
+        char* base = KVG + (size_t)(rank + 1) * 2 * hsz;
+        a.K = base; a.V = base + hsz; a.kv_chunks = nc; a.kv_splits = sc; a.part_slot0 = sa + sb;
+        LCHK(c, wm_launch_attention(a, c.s));
+      }
+      LCHK(c, wm_launch_attention_combine(a, sa + sb + sc, c.s));
+    } else {
+      if (sharded) {
+        // K and V are adjacent: one all-gather of [K|V] per layer -> [world][2][H][M][64]
+        char* KVG = B<char>(h, "KVG");
+        st = comm_allgather(h, K16, KVG, 2 * hsz, c.s);
+        if (st) return st;
+        a.K = KVG; a.V = KVG + hsz; a.seq_len = M; a.kv_head_stride = M; a.kv_chunks = d.world;
+        a.kv_chunk_stride = (long long)(2 * hsz / 2); a.kv_rows_per_chunk = M;
+      } else {
+        a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
+      }
+      ProfScope ps(h, is_global ? 0 : 1, c.s);
+      LCHK(c, wm_launch_attention(a, c.s));
+    }
   }
   st = gemm(c, dt, WM_EPI_RESID, O16, D, W16(h, p + "attn.proj.weight"), D, X, D, F(h, p + "attn.proj.bias"), F(h, p + "ls1.gamma"), M, D, D);
   if (st) return st;
