@@ -1239,10 +1239,13 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
     if (out->camera_poses && out->camera_intrs)
       LCHK(c, wm_launch_cam_matrices(B<float>(h, "cam_params"), out->camera_poses, out->camera_intrs, nt, H, W_, s));
   }
-  // ---- a13: DPT heads (worldmirror.py:74-98).  They are independent of each other and CAN run one per stream
-  // (WM_HEADS_CONCURRENT=1), but that is OFF: with several queues active, kernels of a dependent chain were
-  // measured to read stale 128-B lines of buffers rewritten earlier in the same stream (cross-XCD L2, see
-  // DESIGN.md "Multi-stream finding"); the single-stream path is bit-exact run to run.
+  // ---- a13: DPT heads (worldmirror.py:74-98).  They are independent of each other and run one per stream, forked from / joined
+  // to the caller's stream with events (-0.75 ms per forward at 8 x 518^2: the 37^2 / 19^2 levels fill 128-200 of the 256 CUs).
+  // WM_HEADS_CONCURRENT=0 keeps them on the caller's stream; so does the profiling mode (per-class HIP-event intervals of
+  // parallel streams would overlap).  History: in round 1 results became non-deterministic with several queues active; the cause
+  // was the loop-carried-load waits of the conv kernels (fixed by the register-tied waits, DESIGN.md "hazards"), not the queues:
+  // 100 rounds of 3-queue chains and 12 concurrent-head forwards are bit-identical to the single-queue result
+  // (profiles/r02_multiqueue_*.log, tools/stress_multiqueue.py, tools/micro/multiqueue_repro.cpp).
   {
     struct HeadJob { const char* p; int F; int od; int act; bool gs; float* attr; float* conf; };
     std::vector<HeadJob> jobs;
@@ -1255,7 +1258,8 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
       if (out->splat_means && !(cf.enable_cam && out->camera_params)) return fail(h, WM_ERR_INVALID, "splats need the camera head");
       jobs.push_back({"gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf});
     }
-    static const bool serial = getenv("WM_HEADS_CONCURRENT") == nullptr;
+    static const bool serial_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return e && atoi(e) == 0; }();
+    const bool serial = serial_env || h->prof;
     if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
     if (!serial && jobs.size() > 1) LCHK(c, hipEventRecord(h->hfork, s));
     for (size_t k = 0; k < jobs.size(); ++k) {

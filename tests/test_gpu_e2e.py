@@ -129,7 +129,9 @@ def test_refinit_weights_bf16_meets_north_star(name):
         errs[k] = rel_l2(g, v)
     print(name, {k: f"{e:.2e}" for k, e in errs.items()})
     assert errs["pts3d"] < 1e-3 and errs["depth"] < 1e-3 and errs["normals"] < 1e-3, errs
-    assert errs["camera_params"] < 2e-2 and errs["camera_poses"] < 2e-2, errs
+    # camera outputs: 2 x the measured values (r02: camera_params 4.3e-3 / 5.8e-3, camera_poses 7.0e-3 / 1.2e-2 on the two fixtures;
+    # the rounding-emulated oracle itself sits at 3.4e-3 / 5.1e-3 and 4.9e-3 / 1.2e-2: tests/test_gpu_emulated.py)
+    assert errs["camera_params"] < 1.2e-2 and errs["camera_poses"] < 2.4e-2, errs
 
 
 def test_tiny_gs_branch_golden():
