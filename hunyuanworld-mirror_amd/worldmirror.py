@@ -90,6 +90,36 @@ def extract_priors(views: Dict[str, torch.Tensor]):
     return depths, rays, poses
 
 
+def shard_inputs(views: Dict[str, torch.Tensor], cond_flags, rank: int, world: int, patch_size: int = 14):
+    """The host-side sharding rules of the view-sharded forward, device-agnostic: validate the input dict as the
+    reference does (visual_transformer.py:272-273, patch_embed.py:67-68), normalise the priors over ALL views
+    (worldmirror.py:134-141: cross-view statistics come before sharding), then cut the contiguous block of views
+    [rank * S / world, (rank + 1) * S / world) that this rank owns.  Returns a dict with the local tensors
+    (img [n,3,H,W], pose [n,7] | None, ray [n,4] | None, depth [n,H,W] | None; fp32, contiguous, on the inputs' device) and
+    n, first_view, S, H, W, flags.  Used by WorldMirror.forward and by tests/test_sharding_cpu.py (gloo, world 2)."""
+    imgs = views["img"]
+    if imgs.dim() != 5 or imgs.shape[0] != 1:
+        raise ValueError("views['img'] must be [1, S, 3, H, W] (B is always 1 at inference, infer.py:143)")
+    _, S, ch, H, W = imgs.shape
+    if ch != 3:
+        raise ValueError(f"Expected 3 input channels, got {ch}")  # visual_transformer.py:272-273
+    assert H % patch_size == 0, f"Input image height {H} is not a multiple of patch height {patch_size}"  # patch_embed.py:67-68
+    assert W % patch_size == 0, f"Input image width {W} is not a multiple of patch width: {patch_size}"
+    flags = [int(x) for x in cond_flags]
+    depths = rays = poses = None
+    if sum(flags) > 0:  # worldmirror.py:134-141
+        depths, rays, poses = extract_priors(views)
+    if S % world:
+        raise ValueError(f"{S} views do not shard evenly over {world} ranks")
+    n = S // world
+    v0 = rank * n
+
+    def local(t, shape):
+        return None if t is None else t[0, v0:v0 + n].to(torch.float32).reshape(shape).contiguous()
+    return {"img": local(imgs, (n, 3, H, W)), "pose": local(poses, (n, 7)), "ray": local(rays, (n, 4)), "depth": local(depths, (n, H, W)),
+            "n": n, "first_view": v0, "S": S, "H": H, "W": W, "flags": flags}
+
+
 def prune_gs(splats: Dict[str, torch.Tensor], voxel_size: float = 0.002) -> Dict[str, List[torch.Tensor]]:
     """Weighted voxel merge of the per-pixel splats (rasterization.py:301-387) through ``wm_prune_gs``
     (splat_prune.hip: voxel keys, stable radix sort, one thread per voxel summing in index order).  Same input dict
@@ -351,33 +381,11 @@ class WorldMirror:
             raise RuntimeError("call .to('cuda') first: the forward pass runs in libwm_hip.so on the GPU")
         L = _lib.lib()
         dev = self._device
-        imgs = views["img"]
-        if imgs.dim() != 5 or imgs.shape[0] != 1:
-            raise ValueError("views['img'] must be [1, S, 3, H, W] (B is always 1 at inference, infer.py:143)")
-        _, S, ch, H, W = imgs.shape
-        if ch != 3:
-            raise ValueError(f"Expected 3 input channels, got {ch}")  # visual_transformer.py:272-273
-        ps = self.cfg.patch_size
-        assert H % ps == 0, f"Input image height {H} is not a multiple of patch height {ps}"  # patch_embed.py:67-68
-        assert W % ps == 0, f"Input image width {W} is not a multiple of patch width: {ps}"
-        flags = [int(x) for x in cond_flags]
-        depths = rays = poses = None
-        if sum(flags) > 0:  # worldmirror.py:134-141
-            depths, rays, poses = extract_priors(views)
         rank, world = self._comm if self._comm else (0, 1)
-        if S % world:
-            raise ValueError(f"{S} views do not shard evenly over {world} ranks")
-        n = S // world
-        v0 = rank * n
-
-        def local(t, shape):
-            if t is None:
-                return None
-            return t[0, v0:v0 + n].to(dev, torch.float32).reshape(shape).contiguous()
-        img_l = local(imgs, (n, 3, H, W))
-        pose_l = local(poses, (n, 7))
-        ray_l = local(rays, (n, 4))
-        depth_l = local(depths, (n, H, W))
+        sh = shard_inputs(views, cond_flags, rank, world, self.cfg.patch_size)
+        n, v0, S, H, W, flags = sh["n"], sh["first_view"], sh["S"], sh["H"], sh["W"], sh["flags"]
+        ps = self.cfg.patch_size
+        img_l, pose_l, ray_l, depth_l = [None if sh[k] is None else sh[k].to(dev) for k in ("img", "pose", "ray", "depth")]
 
         o = _lib.wm_outputs()
         res: Dict[str, torch.Tensor] = {}

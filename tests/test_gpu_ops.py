@@ -536,6 +536,37 @@ def test_conv(dev, Cin, Cout, ks, stride, Hh, Ww):
         assert e < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,ks,Hh,Ww", [(256, 256, 3, 37, 37), (256, 128, 3, 40, 40), (64, 64, 3, 20, 16), (256, 256, 1, 16, 16), (128, 32, 3, 30, 30)])
+@pytest.mark.parametrize("scale", [1e5, 1e-6])
+def test_conv_f16_operand_range(dev, Cin, Cout, ks, Hh, Ww, scale):
+    """The reference's DPT heads are fp32 (worldmirror.py:146): activations of a real checkpoint may leave f16's range.  The f16
+    staging SATURATES at +-65504 (wm_common.h f2h): inputs of magnitude 1e5 give finite outputs equal to the conv of the clamped
+    input (an unsaturated cast would feed inf to the MFMA: NaN rows); inputs of magnitude 1e-6 land in f16's subnormals and match
+    the conv of the f16-rounded input.  With head_dtype = bf16 the same inputs are in range: error = plain bf16 operand rounding."""
+    pad = 1 if ks == 3 else 0
+    g = torch.Generator().manual_seed(Cin + Cout + ks)
+    N = 2
+    x = (torch.randn(N, Hh, Ww, Cin, generator=g) * scale).to(dev)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = (torch.randn(Cout, generator=g) * scale).to(dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dt in (F16, BF16):
+        wq = _t16(w, dt).float().to(dev)
+        w16 = _t16(wq.permute(0, 2, 3, 1).contiguous(), dt)
+        y = torch.empty(N, Hh, Ww, Cout, device=dev)
+        assert _lib().wm_op_conv(dt, _p(x), _p(w16), _p(b), None, None, _p(y), N, Hh, Ww, Cin, Cout, ks, 1, pad, 0, 0, s) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all(), (dt, scale)
+        xin = x.clamp(-65504.0, 65504.0) if dt == F16 else x
+        ref = torch.nn.functional.conv2d(_t16(xin, dt).float().permute(0, 3, 1, 2), wq, b, padding=pad).permute(0, 2, 3, 1)
+        e = _rel(y, ref)
+        full = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), wq, b, padding=pad).permute(0, 2, 3, 1)
+        print(f"conv {Cin}->{Cout} k{ks} x{scale:g} dt{dt}: vs same-rounding reference {e:.2e}, vs fp32-activation conv {_rel(y, full):.2e}")
+        assert e < 2e-5
+        if dt == BF16:
+            assert _rel(y, full) < 4e-3  # in range: 8-bit mantissa rounding of the activations only
+
+
 @pytest.mark.parametrize("Cin,Cout,Hh,Ww", [(256, 256, 37, 37), (256, 256, 70, 45), (256, 128, 40, 40), (128, 128, 33, 100), (256, 256, 148, 148)])
 def test_conv3x3_wide_pixel_tile(dev, Cin, Cout, Hh, Ww):
     """conv3x3_rs_kernel with 32 x 8 pixel tiles (chosen automatically where it saves a round over the CUs, e.g. 148^2

@@ -1,9 +1,11 @@
 """CPU, world_size 2, gloo: the view-sharded evaluation of the path equals the unsharded one.
 
 Each rank runs the oracle on its own views; the only exchanges are the per-global-layer all-gather
-of K/V and the camera-token all-gather, carried here by torch.distributed (gloo).  This pins the
-host-side sharding rules the HIP path implements: token slot 0 belongs to GLOBAL view 0, priors are
-normalised over all views before sharding, K/V gather order is irrelevant to softmax.
+of K/V and the camera-token all-gather, carried here by torch.distributed (gloo).  The per-rank inputs
+are cut by the PRODUCT's own host code — hunyuanworld_mirror_amd.worldmirror.shard_inputs, the function
+WorldMirror.forward calls before wm_forward_sharded — so this pins both the rules (token slot 0 belongs to GLOBAL view 0,
+priors are normalised over all views before sharding, K/V gather order is irrelevant to softmax) and the code that applies
+them.  (shard_inputs is pure torch; the HIP library is not loaded here.)
 """
 import os
 import sys
@@ -29,12 +31,14 @@ def _worker(rank, world, port, name, q):
     cfg, views, flags, outs, z = load_golden(name)
     P = torch_weights(cfg)
     tv = {k: torch.from_numpy(v) for k, v in views.items()}
-    S = tv["img"].shape[1]
-    n = S // world
-    v0 = rank * n
-    priors = R.extract_priors(tv) if sum(flags) else None   # cross-view statistics: BEFORE sharding
-    if priors is not None:
-        priors = tuple(None if p is None else p[:, v0:v0 + n] for p in priors)
+    from hunyuanworld_mirror_amd.worldmirror import shard_inputs
+    sh = shard_inputs(tv, flags, rank, world, cfg.patch_size)          # the product's slicing + prior normalisation
+    n, v0 = sh["n"], sh["first_view"]
+    assert v0 == rank * (tv["img"].shape[1] // world) and sh["img"].shape[0] == n
+    # back to the oracle's (depths, rays, poses) tuple with a leading batch axis
+    priors = None
+    if sum(flags):
+        priors = tuple(None if sh[k] is None else sh[k][None] for k in ("depth", "ray", "pose"))
 
     def gather_seq(t):  # [1,H,L,hd] -> [1,H,world*L,hd]
         parts = [torch.empty_like(t) for _ in range(world)]
@@ -47,7 +51,7 @@ def _worker(rank, world, port, name, q):
         return torch.cat(parts, 1)
 
     with torch.no_grad():
-        img = tv["img"][:, v0:v0 + n]
+        img = sh["img"][None]
         taps, psi = R.backbone(P, img, cfg, priors, flags, shard=(v0, gather_seq))
         cam = R.camera_head(P, taps, cfg, tok_gather=gather_tok)
         pts, conf = R.dpt_head(P, "pts_head.", taps, img, psi, cfg, "inv_log")
