@@ -719,7 +719,9 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
     // (tools/bench_attn_tail.py): 8 views 530 -> 480-495 us (+8-10 %), 16 views +8 %, 32 views +4-7 %; the short
     // per-frame sequences (22 key tiles) lose 10 % and are left alone (ntiles >= 64).
     const long tail = blocks % slots;
-    if (!a.force_partial && a_in.kv_splits == 0 && wm_tuning[WM_TUNE_ATTN_SPLITS] <= 0 && lim >= 2 && ntiles >= 64 && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
+    // (the short per-frame sequences — 22 key tiles — lose 10 % with the general kernel and are left alone there; the pipelined
+    //  kernel splits them too: 768 units on 512 slots = 512 whole + 256 x 2 halves = two even rounds)
+    if (!a.force_partial && a_in.kv_splits == 0 && wm_tuning[WM_TUNE_ATTN_SPLITS] <= 0 && lim >= 2 && ntiles >= (use_v3 ? 16 : 64) && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
       auto round_cost = [&](long n) { const long rem = n % slots; return (double)(n / slots) + (rem == 0 ? 0.0 : rem * 2 <= slots ? 0.73 : 1.0); };
       double best_cost = round_cost(tail);
       int bs = 1;
@@ -770,15 +772,16 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   // 64 rows per wave at 2 waves/SIMD with the lazy max for the long cross-view sequences; the short per-frame / DINO sequences
   // (22 key tiles) run 3-10 % faster as 128-row blocks of 32 rows per wave at 3 waves/SIMD (finer q-tiles: 10.75 -> 11 instead
   // of 5.4 -> 6 per frame, and more waves to overlap; tools/bench_attn_qb.py: 84 vs 87 us at 8 views, 287 vs 313 us at 32)
-  // long (cross-view) sequences: the software-pipelined no-max kernel (7) where it applies — bf16, whole 64-key tiles, a flag
-  // workspace — else the general kernel (3); tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views
-  const int qb = forced ? forced : (a.kv_chunks == 1 && a.seq_len <= 2048 ? 4 : 7);
+  // The software-pipelined no-max kernel (7, attention_v3.hip) wherever it applies — bf16, a flag workspace, key segments of
+  // whole 64-key tiles or a single chunk (the ragged last tile is masked there) — else the general kernel: 64 rows per wave at
+  // 2 waves / SIMD (3) for long sequences, 32 rows per wave at 3 waves / SIMD (4) for the short per-frame / DINO ones.
+  // tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views.
+  const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
+  const bool v3ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows >= 512 && (seg_rows % 64 == 0 || a.kv_chunks == 1);
+  int qb = forced ? forced : 7;
+  if (qb == 7 && !v3ok) qb = (a.kv_chunks == 1 && a.seq_len <= 2048) ? 4 : 3;
   if (a.force_partial && qb != 7 && qb != 3) return hipErrorInvalidValue;  // piecewise launches share the 256-row unit numbering
-  if (qb == 7) {  // software-pipelined no-max kernel (attention_v3.hip): bf16, whole 64-key tiles, a flag workspace
-    const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
-    const bool ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows % 64 == 0 && seg_rows >= 512;
-    return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2>(a, s, ok) : launch<WM_T_F16, 4, 2, 2>(a, s, false);
-  }
+  if (qb == 7) return launch<WM_T_BF16, 4, 2, 2>(a, s, true);
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);
   if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0>(a, s);  // eager max (A/B)
   if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0>(a, s);

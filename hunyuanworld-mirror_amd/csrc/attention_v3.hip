@@ -27,8 +27,13 @@
 // K/V tiles stream by LDS-DMA into rings (K 4 deep, V 3 deep: V of tile t is consumed one tile after K of tile t);
 // at the barrier that opens tile t a wave requests K(t+3) and V(t+1): two tile times of flight for every piece, one
 // barrier per tile, counted vmcnt.  f16 P would need the max (5-bit exponent): f16 stays on attention.hip.
+// A key segment that is not a whole number of tiles (the per-frame sequences: 1376 = 21.5 tiles, DINO 1374) is handled in
+// the block's LAST tile only (single-chunk launches): its DMA clamps the row, and the two softmax halves of that tile run a
+// masked variant (P = 0 beyond the last key) — the steady-state loop stays branch-free.
 #include "wm_common.h"
 #include "wm_kernels.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -108,12 +113,13 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   // ---- K/V segments (seg_rows is a multiple of 64: checked by the launcher)
   const int seg_rows = p.kv_chunks > 1 ? p.kv_rows_per_chunk : p.seq_len;
   const int seg_off = p.kv_chunks > 1 ? 0 : seq_row0;
-  const int ntpc = seg_rows / KVB;
+  const int ntpc = (seg_rows + KVB - 1) / KVB;   // a partial last tile only with kv_chunks == 1 (launcher)
   const int ntiles = ntpc * p.kv_chunks;
   const u16* Kb = (const u16*)p.K + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
   const int nt = t1 - t0;  // >= 2 (launcher)
+  const int last_valid = (t1 == ntiles) ? seg_rows - (ntpc - 1) * KVB : KVB;   // valid keys of this block's last tile (wave-uniform)
 
   // DMA: this wave moves pieces {2 wave, 2 wave + 1} of every K tile and of every V tile (source-side permutation builds the
   // XOR-swizzled K rows and the [4 key][32 d] blocked V image, as in attention.hip).  Source = a wave-uniform tile pointer
@@ -130,25 +136,45 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     voff[i] = (uint32_t)(vkey * 64 + vd8 * 8) * 2;
   }
   const uint32_t smem_base = (uint32_t)(size_t)(lds_vp0)smem;
-  const long long chunk_jump = (p.kv_chunk_stride - (long long)ntpc * KVB * 64) * 2;  // bytes from a chunk's end to the next chunk's start
+  const long long chunk_jump = (p.kv_chunk_stride - (long long)ntpc * KVB * 64) * 2;  // bytes from a chunk's end to the next chunk's start (whole tiles)
   const int c0 = t0 / ntpc, j0 = t0 - c0 * ntpc;
   const char* ksrc = (const char*)(Kb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);  // next K tile (wave-uniform)
   const char* vsrc = (const char*)(Vb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);
   int kj = j0, vj = j0;        // tile-in-chunk of the next K / V tile
   int kslot = 0, vslot = 0;    // ring slots of those tiles
+  int kidx = 0, vidx = 0;      // index (within this block's range) of those tiles
+  // partial last tile: rows beyond the segment are clamped to its last row (their scores are masked / their P is 0)
+  auto clamp_off = [&](bool isv, int i) {
+    const int pc = wave * 2 + i;
+    int key, d8;
+    if (!isv) { key = pc * 8 + (lane >> 3); d8 = (lane & 7) ^ ((key >> 1) & 7); }
+    else { const int off = pc * 1024 + lane * 16, blk = off >> 8; key = (blk >> 1) * 4 + ((off >> 6) & 3); d8 = (blk & 1) * 4 + ((off >> 4) & 3); }
+    key = key < last_valid ? key : last_valid - 1;
+    return (uint32_t)(key * 64 + d8 * 8) * 2;
+  };
   auto dma_k = [&]() {
     const uint32_t dst = smem_base + kslot * TILE_B + wave * 2048;
-    dma16(ksrc, koff[0], dst);
-    dma16(ksrc, koff[1], dst + 1024);
-    ksrc += TILE_B;
+    if (last_valid < KVB && kidx == nt - 1) {  // wave-uniform, once per block
+      dma16(ksrc, clamp_off(false, 0), dst);
+      dma16(ksrc, clamp_off(false, 1), dst + 1024);
+    } else {
+      dma16(ksrc, koff[0], dst);
+      dma16(ksrc, koff[1], dst + 1024);
+    }
+    ksrc += TILE_B; ++kidx;
     if (++kj == ntpc) { kj = 0; ksrc += chunk_jump; }
     kslot = kslot == KRING - 1 ? 0 : kslot + 1;
   };
   auto dma_v = [&]() {
     const uint32_t dst = smem_base + VBASE + vslot * TILE_B + wave * 2048;
-    dma16(vsrc, voff[0], dst);
-    dma16(vsrc, voff[1], dst + 1024);
-    vsrc += TILE_B;
+    if (last_valid < KVB && vidx == nt - 1) {
+      dma16(vsrc, clamp_off(true, 0), dst);
+      dma16(vsrc, clamp_off(true, 1), dst + 1024);
+    } else {
+      dma16(vsrc, voff[0], dst);
+      dma16(vsrc, voff[1], dst + 1024);
+    }
+    vsrc += TILE_B; ++vidx;
     if (++vj == ntpc) { vj = 0; vsrc += chunk_jump; }
     vslot = vslot == VRING - 1 ? 0 : vslot + 1;
   };
@@ -232,6 +258,21 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     }
   };
   auto sm = [&](int par) { sm_half(par, 0); sm_half(par, 1); };
+  auto sm_half_masked = [&](int par, int b, int nvalid) {  // the same with P = 0 for the half's keys >= nvalid (last tile of a ragged segment)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 8 * s2 + i, key = (r & 3) + 8 * (r >> 2) + 4 * h;
+        e[i] = key < nvalid ? __builtin_amdgcn_exp2f(st[par][b][r]) : 0.f;
+        lsum[b][i & 1] += e[i];
+      }
+      uint4 u;
+      u.x = pack2bf(e[0], e[1]); u.y = pack2bf(e[2], e[3]); u.z = pack2bf(e[4], e[5]); u.w = pack2bf(e[6], e[7]);
+      pf[par][b][s2] = __builtin_bit_cast(s16x8, u);
+    }
+  };
   // A step is two scheduling regions of 8 MFMA gaps, each gap = 1 MFMA + (1 LDS read) + 2 exp + 3 plain VALU:
   //   region A: QK MFMAs | the 8 V^T fragment reads of THIS step's PV | softmax of q-block 0
   //   region B: PV MFMAs | the 4 K fragment reads of the NEXT step's QK | softmax of q-block 1
@@ -277,7 +318,8 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   // barrier B_j opens step 2j: everybody finished step 2j-1, so K(j-1) and V(j-2) are dead = the slots K(j+3) and V(j+1) go to;
   // the wait leaves only the four youngest pieces (K(j+2), V(j), requested at B_{j-1}) in flight: K(j+1), V(j-1) landed.
   int vs = 0;  // V ring slot of tile j-1
-  for (int j = 1; j < nt; ++j) {
+  auto tile_body = [&](int j, auto masked_c) {
+    constexpr bool MASKED = decltype(masked_c)::value;   // this is the block's last tile and it is partial
     if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -302,24 +344,26 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     // step 2j+1
     qk(1);
     load_v(va, 1);
-    sm_half(0, 0);
+    if constexpr (MASKED) sm_half_masked(0, 0, last_valid); else sm_half(0, 0);
     pipeline8(8);
     __builtin_amdgcn_sched_barrier(0);
     pv(1);
     load_k(kb, 0);   // past the last tile: a dead read of a valid slot (keeps the step branch-free)
-    sm_half(0, 1);
+    if constexpr (MASKED) sm_half_masked(0, 1, last_valid); else sm_half(0, 1);
     pipeline8(4);
     __builtin_amdgcn_sched_barrier(0);
     vs = vs == VRING - 1 ? 0 : vs + 1;
-  }
-  // ---- epilogue: V(nt-1) landed (the last waits were vmcnt(0) + barrier for nt >= 2; nt == 1: the prologue's);
+  };
+  const bool ragged = last_valid < KVB;   // wave-uniform
+  for (int j = 1; j < nt - 1; ++j) tile_body(j, std::false_type{});
+  if (ragged) tile_body(nt - 1, std::true_type{}); else tile_body(nt - 1, std::false_type{});
+  // ---- epilogue: V(nt-1) landed (the last waits were vmcnt(0) + barrier);
   //      step 2nt: PV(2nt-2) + SM(2nt-1); step 2nt+1: PV(2nt-1)
-  if (nt == 1) vs = 0;
   {
     const uint32_t va = lds_v(vs);
     load_v(va, 0);
     pv(0);
-    sm(1);
+    if (ragged) { sm_half_masked(1, 0, last_valid - 32); sm_half_masked(1, 1, last_valid - 32); } else sm(1);
     __builtin_amdgcn_sched_barrier(0);
     load_v(va, 1);
     pv(1);

@@ -277,7 +277,7 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("KVG", (size_t)d.world * 2 * Mv * D * 2);
   add("ATT_PO", (size_t)WM_ATTN_MAX_SPLITS * Mx * D * 4);   // split-KV attention partials (tail round of a launch cut into up to 8 key slices; uniform 4-way split when a sharded launch fits one round): unnormalised O, (max, sum)
   add("ATT_ML", (size_t)WM_ATTN_MAX_SPLITS * Mx * (D / 64) * 2 * 4);
-  add("ATT_FLAGS", wm_attention_max_blocks((int)Mv, (int)Mv, d.heads) * 4);  // per-block fallback flags of the no-max attention kernel
+  add("ATT_FLAGS", wm_attention_max_blocks((int)Mx, d.P < d.Td ? d.P : d.Td, d.heads) * 4);  // per-block fallback flags of the no-max attention kernel
   add("ZERO256", 256);  // zero page for the out-of-image halo pieces of the DMA-fed conv (conv_n32.hip); cleared at the start of every forward
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
@@ -806,7 +806,7 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     static const bool force_gather = getenv("WM_FORCE_GATHER") != nullptr;  // 1-rank test of the collective path
     static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return e ? atoi(e) != 0 : true; }();
     a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
-    if (is_global) a.unit_flags = B<int>(h, "ATT_FLAGS");
+    a.unit_flags = B<int>(h, "ATT_FLAGS");
     const bool sharded = is_global && (d.world > 1 || (force_gather && h->comm.kind != 0));
     const int ntpc = (M + 63) / 64;  // key tiles per rank chunk
     if (sharded && overlap_env && d.world > 1 && ntpc >= 16) {

@@ -344,11 +344,14 @@ def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev):
     return _from16(o, BF16).reshape(R, H, 64), flags
 
 
-@pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0)])
+@pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0),
+                                                     (16, 8, 1376, 1, 0), (16, 3, 1374, 1, 0), (2, 1, 1000, 1, 1), (3, 2, 577, 1, 1)])
 def test_attention_v3_pipelined_no_max_kernel(dev, H, nseq, L, chunks, splits):
     """attention_v3.hip (attn_qb = 7): software-pipelined, no running max.  Same operands -> the general kernel's result up to
     final-rounding flips (2^S / sum 2^S is scale-free, bf16 rounding of P too), fp32 softmax within the bf16 P / O rounding;
-    whole units, uniform splits (chunks > 1), the tail split (16 heads x 43 q-tiles = 688 units on 512 slots) and 2 sequences."""
+    whole units, uniform splits (chunks > 1), the tail split (16 heads x 43 q-tiles = 688 units on 512 slots), 2 sequences, and
+    RAGGED sequences — per-frame 1376 = 21.5 key tiles (8 frames x 6 q-tiles x 16 heads = 768 units: tail split in halves),
+    DINO's 1374 (the last tile has 30 keys: half 0 partly, half 1 fully masked), 1000 and 577 rows."""
     L_ = _lib()
     g = torch.Generator().manual_seed(H * 13 + L + chunks)
     R = nseq * L
