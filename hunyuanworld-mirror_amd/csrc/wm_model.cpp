@@ -89,6 +89,9 @@ struct wm_handle {
   // K/V all-gather of the sharded forward runs on its own queue, under the attention over the local keys
   hipStream_t cstream = nullptr;
   hipEvent_t cfork = nullptr, cjoin = nullptr;
+  // the camera head (HBM-bound weight streaming) runs beside the DPT heads (MFMA-bound) on its own queue
+  hipStream_t camstream = nullptr;
+  hipEvent_t camjoin = nullptr;
   // profiling
   bool prof = false;
   std::vector<EvPair> ev[5];
@@ -465,6 +468,8 @@ extern "C" void wm_destroy(wm_handle* h) {
     if (h->hjoin[i]) (void)hipEventDestroy(h->hjoin[i]);
   }
   if (h->hfork) (void)hipEventDestroy(h->hfork);
+  if (h->camstream) (void)hipStreamDestroy(h->camstream);
+  if (h->camjoin) (void)hipEventDestroy(h->camjoin);
   if (h->cstream) (void)hipStreamDestroy(h->cstream);
   if (h->cfork) (void)hipEventDestroy(h->cfork);
   if (h->cjoin) (void)hipEventDestroy(h->cjoin);
@@ -1231,13 +1236,30 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
     }
   }
 
-  // ---- a11-a12: camera head
+  static const bool serial_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return e && atoi(e) == 0; }();
+  const bool serial = serial_env || h->prof;
+  if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
+  if (!serial) LCHK(c, hipEventRecord(h->hfork, s));
+  // ---- a11-a12: camera head.  864 MB of fp32 weights streamed 4 times for <= 64 rows: HBM-bound (1.3 ms at 8 views), so it runs
+  // on its own queue BESIDE the MFMA-bound DPT heads (which do not depend on it, except the Gaussian head's splat assembly).
+  bool cam_async = false;
   if (cf.enable_cam && out->camera_params) {
-    st = camera_head(c, B<float>(h, "cam_params"));
+    Ctx cc = c;
+    if (!serial) {
+      if (!h->camstream) {
+        LCHK(c, hipStreamCreateWithFlags(&h->camstream, hipStreamNonBlocking));
+        LCHK(c, hipEventCreateWithFlags(&h->camjoin, hipEventDisableTiming));
+      }
+      cc.s = h->camstream;
+      LCHK(c, hipStreamWaitEvent(cc.s, h->hfork, 0));
+      cam_async = true;
+    }
+    st = camera_head(cc, B<float>(h, "cam_params"));
     if (st) return st;
-    LCHK(c, hipMemcpyAsync(out->camera_params, B<float>(h, "cam_params"), (size_t)nt * 9 * 4, hipMemcpyDeviceToDevice, s));
+    LCHK(c, hipMemcpyAsync(out->camera_params, B<float>(h, "cam_params"), (size_t)nt * 9 * 4, hipMemcpyDeviceToDevice, cc.s));
     if (out->camera_poses && out->camera_intrs)
-      LCHK(c, wm_launch_cam_matrices(B<float>(h, "cam_params"), out->camera_poses, out->camera_intrs, nt, H, W_, s));
+      LCHK(c, wm_launch_cam_matrices(B<float>(h, "cam_params"), out->camera_poses, out->camera_intrs, nt, H, W_, cc.s));
+    if (cam_async) LCHK(c, hipEventRecord(h->camjoin, cc.s));
   }
   // ---- a13: DPT heads (worldmirror.py:74-98).  They are independent of each other and run one per stream, forked from / joined
   // to the caller's stream with events (-0.75 ms per forward at 8 x 518^2: the 37^2 / 19^2 levels fill 128-200 of the 256 CUs).
@@ -1258,18 +1280,15 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
       if (out->splat_means && !(cf.enable_cam && out->camera_params)) return fail(h, WM_ERR_INVALID, "splats need the camera head");
       jobs.push_back({"gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf});
     }
-    static const bool serial_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return e && atoi(e) == 0; }();
-    const bool serial = serial_env || h->prof;
-    if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
-    if (!serial && jobs.size() > 1) LCHK(c, hipEventRecord(h->hfork, s));
     for (size_t k = 0; k < jobs.size(); ++k) {
       Ctx hc = c;
-      if (!serial && jobs.size() > 1) {
+      if (!serial && (jobs.size() > 1 || cam_async)) {
         if (!h->hstream[k]) LCHK(c, hipStreamCreateWithFlags(&h->hstream[k], hipStreamNonBlocking));
         if (!h->hjoin[k]) LCHK(c, hipEventCreateWithFlags(&h->hjoin[k], hipEventDisableTiming));
         hc.s = h->hstream[k];
         LCHK(c, hipStreamWaitEvent(hc.s, h->hfork, 0));
       }
+      if (jobs[k].gs && cam_async) LCHK(c, hipStreamWaitEvent(hc.s, h->camjoin, 0));  // the splats are unprojected with the predicted cameras
       st = dpt_head(hc, jobs[k].p, jobs[k].F, jobs[k].od, jobs[k].act, jobs[k].gs, jobs[k].attr, jobs[k].conf, img, out, first_view, (int)k);
       if (st) return st;
       if (hc.s != s) {
@@ -1278,6 +1297,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
       }
     }
   }
+  if (cam_async) LCHK(c, hipStreamWaitEvent(s, h->camjoin, 0));
   return WM_OK;
 }
 
