@@ -46,14 +46,15 @@ static size_t diff(const float* dev, const std::vector<float>& ref, std::vector<
 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 12;
+  const int NQ = argc > 2 ? atoi(argv[2]) : 3;   // queues = independent chains
   int rt = 0, drv = 0;
   CK(hipRuntimeGetVersion(&rt)); CK(hipDriverGetVersion(&drv));
   printf("hip runtime %d driver %d\n", rt, drv);
   const size_t nin = (size_t)N * Hh * Hh * Cc, nup = (size_t)N * Ho * Ho * Cc, nw = (size_t)Cc * 9 * Cc;
-  Job jobs[3];
+  std::vector<Job> jobs(NQ);
   std::vector<float> h(nin), hw(nw), hb(Cc);
   std::vector<uint16_t> hw16(nw);
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < NQ; ++k) {
     std::mt19937 g(k + 1);
     std::normal_distribution<float> nd(0.f, 1.f);
     Job& j = jobs[k];
@@ -68,7 +69,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&j.b, Cc * 4)); CK(hipMemcpy(j.b, hb.data(), Cc * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&j.buf[0], nin * 4)); CK(hipMalloc(&j.buf[1], nin * 4)); CK(hipMalloc(&j.up, nup * 4));
   }
-  hipStream_t s0, st[3];
+  hipStream_t s0;
+  std::vector<hipStream_t> st(NQ);
   CK(hipStreamCreate(&s0));
   for (auto& s : st) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   for (auto& j : jobs) {  // single-queue reference
@@ -82,19 +84,19 @@ int main(int argc, char** argv) {
   std::vector<float> tmp;
   size_t bad_single = 0, bad_multi = 0;
   for (int r = 0; r < rounds; ++r) {  // single queue again: must be bit-exact
-    for (int k = 0; k < 3; ++k) chain(jobs[k], s0);
+    for (int k = 0; k < NQ; ++k) chain(jobs[k], s0);
     CK(hipDeviceSynchronize());
-    for (int k = 0; k < 3; ++k) bad_single += diff(jobs[k].up, jobs[k].ref_up, tmp, "up (single queue)", k, r);
+    for (int k = 0; k < NQ; ++k) bad_single += diff(jobs[k].up, jobs[k].ref_up, tmp, "up (single queue)", k, r);
   }
   for (int r = 0; r < rounds; ++r) {  // three queues
-    for (int k = 0; k < 3; ++k) chain(jobs[k], st[k]);
+    for (int k = 0; k < NQ; ++k) chain(jobs[k], st[k]);
     CK(hipDeviceSynchronize());
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NQ; ++k) {
       bad_multi += diff(jobs[k].buf[1], jobs[k].ref_b1, tmp, "conv2 out", k, r);
       bad_multi += diff(jobs[k].buf[0], jobs[k].ref_b0, tmp, "conv3 out", k, r);
       bad_multi += diff(jobs[k].up, jobs[k].ref_up, tmp, "bilinear out", k, r);
     }
   }
-  printf("RESULT single-queue wrong words %zu, three-queue wrong words %zu over %d rounds\n", bad_single, bad_multi, rounds);
+  printf("RESULT single-queue wrong words %zu, %d-queue wrong words %zu over %d rounds\n", bad_single, NQ, bad_multi, rounds);
   return 0;
 }

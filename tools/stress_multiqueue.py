@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, '.')
 
 
-def part_a(rounds):
+def part_a(rounds, nq=3):
     from hunyuanworld_mirror_amd import _lib
     L = _lib.lib(); dev = torch.device('cuda:0')
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
@@ -25,7 +25,7 @@ def part_a(rounds):
         assert L.wm_op_conv(1, p(d['bufs'][0]), p(d['ws'][1]), p(d['b']), None, None, p(d['bufs'][1]), N, Hh, Hh, Cc, Cc, 3, 1, 1, 1, 0, s) == 0
         assert L.wm_op_conv(1, p(d['bufs'][1]), p(d['ws'][2]), p(d['b']), None, None, p(d['bufs'][0]), N, Hh, Hh, Cc, Cc, 3, 1, 1, 1, 0, s) == 0
         assert L.wm_op_bilinear(p(d['bufs'][0]), p(d['up']), N, Hh, Hh, 518, 518, Cc, s) == 0
-    jobs = [mk(1), mk(2), mk(3)]
+    jobs = [mk(i + 1) for i in range(nq)]
     s0 = torch.cuda.current_stream()
     ref = []
     for j in jobs:
@@ -68,8 +68,11 @@ if __name__ == "__main__":
         sys.exit(0)
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     fwd = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    nq = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     import hunyuanworld_mirror_amd  # noqa
-    print(json.dumps({"part": "A", "hip_runtime": torch.version.hip, "rounds": rounds, "streams": 3, "wrong_words": part_a(rounds)}), flush=True)
+    print(json.dumps({"part": "A", "hip_runtime": torch.version.hip, "rounds": rounds, "streams": nq, "wrong_words": part_a(rounds, nq)}), flush=True)
+    if fwd <= 0:
+        sys.exit(0)
     res = {}
     for mode in ("serial", "concurrent"):
         env = dict(os.environ)
