@@ -809,7 +809,8 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     memset(&a, 0, sizeof(a));
     a.Q = Q16; a.O = O16; a.H = heads; a.q_rows = M; a.q_head_stride = M; a.dtype = dt;
     static const bool force_gather = getenv("WM_FORCE_GATHER") != nullptr;  // 1-rank test of the collective path
-    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return e ? atoi(e) != 0 : true; }();
+    // opt-in (WM_COMM_OVERLAP=1): a second active queue exposes the packed-fp32 hazard described at the DPT heads below
+    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return e && atoi(e) != 0; }();
     a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
     a.unit_flags = B<int>(h, "ATT_FLAGS");
     const bool sharded = is_global && (d.world > 1 || (force_gather && h->comm.kind != 0));
@@ -1236,8 +1237,15 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
     }
   }
 
-  static const bool serial_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return e && atoi(e) == 0; }();
-  const bool serial = serial_env || h->prof;
+  // One queue by default.  WM_HEADS_CONCURRENT=1 forks the camera head and the DPT heads onto the handle's own queues (-1.7 ms per
+  // forward at 8 x 518^2) — OPT-IN, because kernels of DIFFERENT kinds sharing a SIMD expose a packed-fp32 hazard on this
+  // toolchain / chip: with >= 2 queues active, a compiler-generated v_pk_mul_f32 / v_pk_fma_f32 (op_sel forms) occasionally drops one
+  // half's result in 16-lane groups (inputs read correctly, one fma term missing; never with one queue; gone when the kernel is
+  // built without SLP-packed fp32).  Reproduced WITHOUT torch on the ROCm 7.2 runtime with the library's own kernels:
+  // tools/micro/splat_hazard_repro.cpp, profiles/r02_multiqueue_hazard.md.  All kernels are therefore built -fno-slp-vectorize, and
+  // the product path keeps one queue unless asked.
+  static const bool conc_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return e && atoi(e) != 0; }();
+  const bool serial = !conc_env || h->prof;
   if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
   if (!serial) LCHK(c, hipEventRecord(h->hfork, s));
   // ---- a11-a12: camera head.  864 MB of fp32 weights streamed 4 times for <= 64 rows: HBM-bound (1.3 ms at 8 views), so it runs
@@ -1261,13 +1269,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
       LCHK(c, wm_launch_cam_matrices(B<float>(h, "cam_params"), out->camera_poses, out->camera_intrs, nt, H, W_, cc.s));
     if (cam_async) LCHK(c, hipEventRecord(h->camjoin, cc.s));
   }
-  // ---- a13: DPT heads (worldmirror.py:74-98).  They are independent of each other and run one per stream, forked from / joined
-  // to the caller's stream with events (-0.75 ms per forward at 8 x 518^2: the 37^2 / 19^2 levels fill 128-200 of the 256 CUs).
-  // WM_HEADS_CONCURRENT=0 keeps them on the caller's stream; so does the profiling mode (per-class HIP-event intervals of
-  // parallel streams would overlap).  History: in round 1 results became non-deterministic with several queues active; the cause
-  // was the loop-carried-load waits of the conv kernels (fixed by the register-tied waits, DESIGN.md "hazards"), not the queues:
-  // 100 rounds of 3-queue chains and 12 concurrent-head forwards are bit-identical to the single-queue result
-  // (profiles/r02_multiqueue_*.log, tools/stress_multiqueue.py, tools/micro/multiqueue_repro.cpp).
+  // ---- a13: DPT heads (worldmirror.py:74-98): independent of each other; one per queue only with WM_HEADS_CONCURRENT=1 (see above).
   {
     struct HeadJob { const char* p; int F; int od; int act; bool gs; float* attr; float* conf; };
     std::vector<HeadJob> jobs;
@@ -1473,6 +1475,11 @@ extern "C" wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w1
   a.x = (const uint16_t*)up16; a.w = (const uint16_t*)w16; a.bias = bias; a.y = y; a.zero = zero;
   a.N = N; a.H = Hi; a.W = Wi; a.Cin = Cin; a.relu_out = relu_out; a.dtype = dtype;
   return wm_launch_conv3x3_n32_in16(a, s) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+// splat assembly of prepare_splats (rasterization.py:389-498) as an operator: used by tools/micro/splat_hazard_repro.cpp
+extern "C" wm_status wm_op_gs_splat(const float* gp, const float* img, const float* depth, const float* cam, float* means, float* quats,
+                                    float* scales, float* opac, float* sh, float* wts, int N, int H, int W, void* stream) {
+  return wm_launch_gs_splat(gp, img, depth, cam, means, quats, scales, opac, sh, wts, N, H, W, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
 extern "C" size_t wm_prune_gs_workspace_bytes(size_t n) { return wm_prune_workspace_bytes(n); }
 extern "C" wm_status wm_prune_gs(const float* means, const float* quats, const float* scales, const float* opacities, const float* sh,

@@ -147,6 +147,10 @@ wm_status wm_op_attention_ex(int dtype, const void* Q, const void* K, const void
                              int kv_chunks, int kv_rows_per_chunk, int kv_splits, float* part_o, float* part_ml, int* unit_flags,
                              void* stream);
 size_t wm_op_attention_flag_count(int q_rows, int seq_len, int H);
+/* prepare_splats' per-pixel assembly (src/models/models/rasterization.py:389-498, position_from = "gsdepth+predcamera"): gp [N*H*W][12]
+ * raw head outputs, img [N][3][H][W], depth [N][H][W], cam [N][9] -> means / quats / scales / opacities / sh / weights */
+wm_status wm_op_gs_splat(const float* gp, const float* img, const float* depth, const float* cam, float* means, float* quats,
+                         float* scales, float* opac, float* sh, float* wts, int N, int H, int W, void* stream);
 wm_status wm_op_layernorm(const float* x, void* y, const float* w, const float* b, int rows, int D, float eps, int out_f32,
                           int dtype, void* stream);
 wm_status wm_op_qkv_post(int dtype, const float* qkv, void* q, void* k, void* v, const float* qn_w, const float* qn_b,
