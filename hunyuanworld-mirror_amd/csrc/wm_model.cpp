@@ -430,7 +430,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -815,7 +815,8 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     a.unit_flags = B<int>(h, "ATT_FLAGS");
     const bool sharded = is_global && (d.world > 1 || (force_gather && h->comm.kind != 0));
     const int ntpc = (M + 63) / 64;  // key tiles per rank chunk
-    if (sharded && overlap_env && d.world > 1 && ntpc >= 16) {
+    const bool overlap = wm_tuning[WM_TUNE_COMM_OVERLAP] >= 0 ? wm_tuning[WM_TUNE_COMM_OVERLAP] != 0 : overlap_env;
+    if (sharded && overlap && d.world > 1 && ntpc >= 16) {
       // ---- K/V all-gather UNDER the attention over this rank's own keys: the collective runs on the handle's
       // communication queue as soon as the QKV epilogue has written K|V; the compute queue meanwhile attends the local chunk
       // (1 / world of the keys: about the gather's own duration at 8 ranks), then the remote chunks — the gathered buffer's
@@ -1245,7 +1246,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   // tools/micro/splat_hazard_repro.cpp, profiles/r02_multiqueue_hazard.md.  All kernels are therefore built -fno-slp-vectorize, and
   // the product path keeps one queue unless asked.
   static const bool conc_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return e && atoi(e) != 0; }();
-  const bool serial = !conc_env || h->prof;
+  const bool serial = !(wm_tuning[WM_TUNE_HEADS_CONC] >= 0 ? wm_tuning[WM_TUNE_HEADS_CONC] != 0 : conc_env) || h->prof;
   if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
   if (!serial) LCHK(c, hipEventRecord(h->hfork, s));
   // ---- a11-a12: camera head.  864 MB of fp32 weights streamed 4 times for <= 64 rows: HBM-bound (1.3 ms at 8 views), so it runs

@@ -47,6 +47,24 @@ def test_c2_deterministic(model_and_out):
         assert torch.equal(again[k], out[k]), k                       # no atomics / races anywhere on the path
 
 
+def test_c2_concurrent_heads_opt_in_is_bit_identical(model_and_out):
+    """WM_HEADS_CONCURRENT=1 (here: the tuning key): camera head + DPT heads on the handle's own queues.  Opt-in because of the
+    packed-fp32 multi-queue hazard (profiles/r02_multiqueue_hazard.md); with every kernel built -fno-slp-vectorize the forward must
+    be bit-identical to the single-queue one — 6 forwards."""
+    from hunyuanworld_mirror_amd import _lib
+    m, img, out = model_and_out
+    L = _lib.lib()
+    assert L.wm_set_tuning(b"heads_concurrent", 1) == 0
+    try:
+        for _ in range(6):
+            again = m({"img": img})
+            torch.cuda.synchronize()
+            for k in ("pts3d", "depth", "normals", "camera_params", "pts3d_conf", "depth_conf", "normals_conf", "camera_poses"):
+                assert torch.equal(again[k], out[k]), k
+    finally:
+        L.wm_set_tuning(b"heads_concurrent", -1)
+
+
 def test_c2_view_permutation_equivariance(model_and_out):
     """Views 1..N-1 are exchangeable (only view 0 carries the reference-frame tokens,
     visual_transformer.py:397-416): swapping two of them swaps their outputs.  Not bitwise: the key order of the
@@ -156,6 +174,20 @@ def test_c4_shapes_eight_virtual_ranks(model_and_out):
         assert torch.isfinite(a[k]).all(), k
         assert torch.equal(a[k], b[k]), k
     del b
+    # the same with the K/V all-gather on the communication queue under the attention over the local keys (opt-in in the product:
+    # WM_COMM_OVERLAP=1): three partial launches per layer (own chunk | chunks before | chunks after) + one combine pass
+    assert L.wm_set_tuning(b"comm_overlap", 1) == 0
+    try:
+        c1 = sharded()
+        c2 = sharded()
+    finally:
+        L.wm_set_tuning(b"comm_overlap", -1)
+    for k in a:
+        assert torch.equal(c1[k], c2[k]), k
+        e = rel_l2(c1[k].cpu().numpy(), a[k].cpu().numpy())
+        print("C4 overlapped gather vs gather on the compute queue", k, f"{e:.2e}")
+        assert e < 2.5e-3, (k, e)   # another summation order over the key chunks: the decorrelation floor again
+    del c1, c2
     single = owner({"img": img})
     torch.cuda.synchronize()
     for k in ("pts3d", "depth", "normals", "pts3d_conf", "camera_params"):
