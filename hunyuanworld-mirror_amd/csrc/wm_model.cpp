@@ -94,8 +94,8 @@ struct wm_handle {
   hipEvent_t camjoin = nullptr;
   // profiling
   bool prof = false;
-  std::vector<EvPair> ev[5];
-  size_t ev_used[5] = {0, 0, 0, 0, 0};
+  std::vector<EvPair> ev[8];
+  size_t ev_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -473,7 +473,7 @@ extern "C" void wm_destroy(wm_handle* h) {
   if (h->cstream) (void)hipStreamDestroy(h->cstream);
   if (h->cfork) (void)hipEventDestroy(h->cfork);
   if (h->cjoin) (void)hipEventDestroy(h->cjoin);
-  for (int k = 0; k < 5; ++k)
+  for (int k = 0; k < 8; ++k)
     for (auto& e : h->ev[k]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (h->comm.kind == 1 && h->comm.nccl) ncclCommDestroy(h->comm.nccl);
   delete h;
@@ -757,7 +757,8 @@ wm_status gemm(Ctx& c, int dt, int epi, const void* A, int lda, const void* Wp, 
   if (extra) a = *extra; else memset(&a, 0, sizeof(a));
   a.A = A; a.W = Wp; a.C = C; a.bias = bias; a.gamma = gamma;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.dtype = dt; a.epi = epi;
-  ProfScope ps(c.h, 2, c.s);
+  // timing kinds by kernel instantiation: the three epilogues that carry the transformer blocks, the rest under 2
+  ProfScope ps(c.h, epi == WM_EPI_QKV ? 5 : epi == WM_EPI_RESID ? 6 : epi == WM_EPI_GELU_T16 ? 7 : 2, c.s);
   LCHK(c, wm_launch_gemm(a, c.s));
   return WM_OK;
 }
@@ -1159,7 +1160,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   if (!(h->plan_n == d.n && h->plan_nt == d.nt && h->plan_H == d.H && h->plan_W == d.W))
     return fail(h, WM_ERR_STATE, "no workspace for this shape: call wm_reserve(h, n_local, n_total, H, W) first (and again after loading weights)");
   wm_status st = WM_OK;
-  for (int k = 0; k < 5; ++k) h->ev_used[k] = 0;
+  for (int k = 0; k < 8; ++k) h->ev_used[k] = 0;
   ProfScope whole(h, 4, s);
   HIPCHK(h, hipMemsetAsync(B<char>(h, "ZERO256"), 0, 256, s));
   const int D = d.D;
@@ -1384,7 +1385,7 @@ extern "C" wm_status wm_profile_enable(wm_handle* h, int on) {
   return WM_OK;
 }
 extern "C" wm_status wm_profile_read(wm_handle* h, int kind, double* total_ms, int64_t* launches) {
-  if (!h || kind < 0 || kind > 4) return WM_ERR_INVALID;
+  if (!h || kind < 0 || kind > 7) return WM_ERR_INVALID;
   double tot = 0;
   for (size_t i = 0; i < h->ev_used[kind]; ++i) {
     float ms = 0;
