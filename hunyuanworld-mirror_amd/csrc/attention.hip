@@ -772,14 +772,16 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   // 64 rows per wave at 2 waves/SIMD with the lazy max for the long cross-view sequences; the short per-frame / DINO sequences
   // (22 key tiles) run 3-10 % faster as 128-row blocks of 32 rows per wave at 3 waves/SIMD (finer q-tiles: 10.75 -> 11 instead
   // of 5.4 -> 6 per frame, and more waves to overlap; tools/bench_attn_qb.py: 84 vs 87 us at 8 views, 287 vs 313 us at 32)
-  // The software-pipelined no-max kernel (7, attention_v3.hip) wherever it applies — bf16, a flag workspace, key segments of
-  // whole 64-key tiles or a single chunk (the ragged last tile is masked there) — else the general kernel: 64 rows per wave at
-  // 2 waves / SIMD (3) for long sequences, 32 rows per wave at 3 waves / SIMD (4) for the short per-frame / DINO ones.
-  // tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views.
+  // The software-pipelined no-max kernel (7, attention_v3.hip) for bf16 with a flag workspace and key segments of whole
+  // 64-key tiles (the cross-view sequences) — else the general kernel: 64 rows per wave at 2 waves / SIMD (3) for long
+  // sequences, 32 rows per wave at 3 waves / SIMD (4) for the short per-frame / DINO ones.
+  // tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views.  The per-frame / DINO sequences
+  // (1376 / 1374 keys = 21.5 tiles) have a ragged last tile: the v3 instantiation that masks it needs one wave per SIMD and
+  // loses to (4) there (122 vs 86 us at 8 views), so it runs only when forced (WM_ATTN_QB=7 / tuning: the parity tests do).
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
   const bool v3ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows >= 512 && (seg_rows % 64 == 0 || a.kv_chunks == 1);
-  int qb = forced ? forced : 7;
-  if (qb == 7 && !v3ok) qb = (a.kv_chunks == 1 && a.seq_len <= 2048) ? 4 : 3;
+  int qb = forced ? forced : (seg_rows % 64 == 0 ? 7 : 0);
+  if ((qb == 7 && !v3ok) || qb == 0) qb = (a.kv_chunks == 1 && a.seq_len <= 2048) ? 4 : 3;
   if (a.force_partial && qb != 7 && qb != 3) return hipErrorInvalidValue;  // piecewise launches share the 256-row unit numbering
   if (qb == 7) return launch<WM_T_BF16, 4, 2, 2>(a, s, true);
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);

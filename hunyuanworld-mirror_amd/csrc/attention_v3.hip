@@ -66,7 +66,9 @@ __device__ __forceinline__ void dma16(const void* sbase, uint32_t voff, uint32_t
 #define SG_DSRD 0x100
 #define SG_TRANS 0x400
 
-template <int MINW>
+// RAGGED: the instantiation for segments that are not whole tiles (per-frame sequences); the cross-view instantiation carries
+// none of that code (its register budget is exact: 236 VGPRs, two waves per SIMD, no scratch)
+template <int MINW, bool RAGGED>
 __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, int* __restrict__ flags) {
   constexpr int QB = 2, QT = 256;
   __shared__ __attribute__((aligned(16))) char smem[(KRING + VRING) * TILE_B];  // K ring | V ring
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
   const int nt = t1 - t0;  // >= 2 (launcher)
-  const int last_valid = (t1 == ntiles) ? seg_rows - (ntpc - 1) * KVB : KVB;   // valid keys of this block's last tile (wave-uniform)
+  const int last_valid = (RAGGED && t1 == ntiles) ? seg_rows - (ntpc - 1) * KVB : KVB;   // valid keys of this block's last tile (wave-uniform)
 
   // DMA: this wave moves pieces {2 wave, 2 wave + 1} of every K tile and of every V tile (source-side permutation builds the
   // XOR-swizzled K rows and the [4 key][32 d] blocked V image, as in attention.hip).  Source = a wave-uniform tile pointer
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   };
   auto dma_k = [&]() {
     const uint32_t dst = smem_base + kslot * TILE_B + wave * 2048;
-    if (last_valid < KVB && kidx == nt - 1) {  // wave-uniform, once per block
+    if (RAGGED && last_valid < KVB && kidx == nt - 1) {  // wave-uniform, once per block
       dma16(ksrc, clamp_off(false, 0), dst);
       dma16(ksrc, clamp_off(false, 1), dst + 1024);
     } else {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   };
   auto dma_v = [&]() {
     const uint32_t dst = smem_base + VBASE + vslot * TILE_B + wave * 2048;
-    if (last_valid < KVB && vidx == nt - 1) {
+    if (RAGGED && last_valid < KVB && vidx == nt - 1) {
       dma16(vsrc, clamp_off(true, 0), dst);
       dma16(vsrc, clamp_off(true, 1), dst + 1024);
     } else {
@@ -354,16 +356,22 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     __builtin_amdgcn_sched_barrier(0);
     vs = vs == VRING - 1 ? 0 : vs + 1;
   };
-  const bool ragged = last_valid < KVB;   // wave-uniform
-  for (int j = 1; j < nt - 1; ++j) tile_body(j, std::false_type{});
-  if (ragged) tile_body(nt - 1, std::true_type{}); else tile_body(nt - 1, std::false_type{});
+  const bool ragged = RAGGED && last_valid < KVB;   // wave-uniform
+  if constexpr (RAGGED) {
+    for (int j = 1; j < nt - 1; ++j) tile_body(j, std::false_type{});
+    if (ragged) tile_body(nt - 1, std::true_type{}); else tile_body(nt - 1, std::false_type{});
+  } else {
+    for (int j = 1; j < nt; ++j) tile_body(j, std::false_type{});
+  }
   // ---- epilogue: V(nt-1) landed (the last waits were vmcnt(0) + barrier);
   //      step 2nt: PV(2nt-2) + SM(2nt-1); step 2nt+1: PV(2nt-1)
   {
     const uint32_t va = lds_v(vs);
     load_v(va, 0);
     pv(0);
-    if (ragged) { sm_half_masked(1, 0, last_valid - 32); sm_half_masked(1, 1, last_valid - 32); } else sm(1);
+    if constexpr (RAGGED) {
+      if (ragged) { sm_half_masked(1, 0, last_valid - 32); sm_half_masked(1, 1, last_valid - 32); } else sm(1);
+    } else sm(1);
     __builtin_amdgcn_sched_barrier(0);
     load_v(va, 1);
     pv(1);
@@ -421,7 +429,11 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
 
 // grid / split decisions are the caller's (attention.hip: the same unit numbering as attn_fwd_kernel<.., 4, 2, ..>)
 hipError_t wm_launch_attention_v3(const WmAttnArgs& a, int grid, int* flags, int minw, hipStream_t s) {
-  if (minw >= 2) hipLaunchKernelGGL((attn_v3_kernel<2>), dim3(grid), dim3(256), 0, s, a, flags);
-  else hipLaunchKernelGGL((attn_v3_kernel<1>), dim3(grid), dim3(256), 0, s, a, flags);
+  const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
+  if (seg_rows % KVB) {
+    if (a.kv_chunks > 1) return hipErrorInvalidValue;   // a partial tile only at the end of a single segment
+    hipLaunchKernelGGL((attn_v3_kernel<1, true>), dim3(grid), dim3(256), 0, s, a, flags);
+  } else if (minw >= 2) hipLaunchKernelGGL((attn_v3_kernel<2, false>), dim3(grid), dim3(256), 0, s, a, flags);
+  else hipLaunchKernelGGL((attn_v3_kernel<1, false>), dim3(grid), dim3(256), 0, s, a, flags);
   return hipGetLastError();
 }

@@ -1,0 +1,45 @@
+"""Register budget of the pipelined cross-view attention kernel (attention_v3.hip), checked at compile time — no GPU needed.
+
+The kernel's schedule assumes two waves per SIMD with nothing in scratch: a change that pushes it over 256 VGPRs still compiles
+and still passes parity, but runs ~20 % slower (measured: 1240 -> 1030 TF/s at 32 views when a variant spilled 108 registers).
+hipcc's resource remarks are the check.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "hunyuanworld-mirror_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_attention_v3_fits_two_waves_per_simd_without_scratch(tmp_path):
+    flags = None
+    for line in open(os.path.join(CSRC, "Makefile")):
+        if line.startswith("CXXFLAGS"):
+            flags = line.split("=", 1)[1].split()
+    assert flags, "CXXFLAGS not found in the Makefile"
+    flags = [f.replace("$(ARCH)", "gfx950") for f in flags if not f.startswith("$(")]
+    assert "--offload-arch=gfx950" in flags
+    cmd = ["hipcc", *flags, "-x", "hip", "-c", os.path.join(CSRC, "attention_v3.hip"), "-o", str(tmp_path / "a.o"),
+           "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # remarks come as blocks: "Function Name: X" followed by that function's figures
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = {}
+    for b in blocks:
+        name = b.split()[0]
+        get = lambda key: int(re.search(key + r": (\d+)", b).group(1))
+        seen[name] = {"vgpr": get(r"VGPRs"), "scratch": get(r"ScratchSize \[bytes/lane\]"), "occ": get(r"Occupancy \[waves/SIMD\]"),
+                      "spill": get(r"VGPRs Spill")}
+    main = [v for k, v in seen.items() if "attn_v3_kernelILi2ELb0E" in k]
+    assert len(main) == 1, list(seen)
+    m = main[0]
+    assert m["scratch"] == 0 and m["spill"] == 0 and m["occ"] >= 2 and m["vgpr"] <= 256, m
+    for k, v in seen.items():       # no instantiation may use scratch
+        assert v["scratch"] == 0 and v["spill"] == 0, (k, v)
