@@ -29,7 +29,7 @@ PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA, guides/MI355X_MICROARCH.md "Chip-l
 # timing kinds of wm_profile_read (include/wm_hip.h): one per kernel instantiation that matters; "gemm" in the class table is
 # the sum of the four gemm_* rows
 KINDS = {0: "global_attention", 1: "frame_dino_attention", 5: "gemm_qkv", 6: "gemm_proj_fc2", 7: "gemm_fc1", 2: "gemm_other",
-         3: "dpt_conv"}
+         8: "dpt_conv3x3_level4x", 9: "dpt_conv3x3_level2x", 10: "dpt_output_conv1_up", 11: "dpt_output_conv2_tail", 3: "dpt_conv_other"}
 
 
 def flop_model(cfg, n_local, n_total, H, W, heads=3):
@@ -46,7 +46,17 @@ def flop_model(cfg, n_local, n_total, H, W, heads=3):
     attn_global = cfg.depth * 4 * (n_local * P) * (n_total * P) * D
     # DPT head: per view, scaled from the 518-px figure of BASELINE.md (298.6 GF) by pixel count
     dpt = heads * 298.6e9 * (H * W) / (518.0 * 518.0) * n_local if D == 1024 else 0.0
-    return {"gemm": gemm, "gemm_qkv": toks * 2 * D * 3 * D, "gemm_proj_fc2": toks * 2 * D * (D + cfg.mlp_ratio * D),
+    F = cfg.dpt_features
+    gh, gw = H // ps, W // ps
+    c33 = lambda px, ci, co: 2.0 * px * ci * co * 9
+    # per head: layer_rn + 2 RCUs (4 convs) on each of the two large levels; output_conv1 at 8x; output_conv2[0] + the 1x1 tail at full size
+    d4 = heads * n_local * 5 * c33(16 * gh * gw, F, F)
+    d2 = heads * n_local * 5 * c33(4 * gh * gw, F, F)
+    d_up = heads * n_local * c33(64 * gh * gw, F, F // 2)
+    d_tail = heads * n_local * (c33(H * W, F // 2, 32) + 2.0 * H * W * 32 * 4)
+    return {"dpt_conv3x3_level4x": d4, "dpt_conv3x3_level2x": d2, "dpt_output_conv1_up": d_up, "dpt_output_conv2_tail": d_tail,
+            "dpt_conv_other": max(dpt - d4 - d2 - d_up - d_tail, 0.0),
+            "gemm": gemm, "gemm_qkv": toks * 2 * D * 3 * D, "gemm_proj_fc2": toks * 2 * D * (D + cfg.mlp_ratio * D),
             "gemm_fc1": toks * 2 * D * cfg.mlp_ratio * D, "gemm_other": g_other, "frame_dino_attention": attn_local, "global_attention": attn_global, "dpt_conv": dpt,
             "total": gemm + attn_local + attn_global + dpt + 1.6e9 * n_total}
 
@@ -179,12 +189,13 @@ def main():
     whole_ms, _ = m.profile_read(4)
     m.profile(False)
     kernels = dict(classes)                 # per kernel instantiation
-    gk = [k for k in classes if k.startswith("gemm_")]
-    if gk:                                  # the GEMM class as a whole (r01's row), beside its kernels
-        gms, gn = sum(classes[k]["ms_total"] for k in gk), sum(classes[k]["launches"] for k in gk)
-        classes = {k: v for k, v in classes.items() if not k.startswith("gemm_")}
-        classes["gemm"] = {"ms_total": round(gms, 3), "launches": gn, "avg_ms": round(gms / gn, 4),
-                           "tflops": round(fl["gemm"] / (gms * 1e-3) / 1e12, 1)}
+    for cls, pre in (("gemm", "gemm_"), ("dpt_conv", "dpt_")):   # the classes as a whole (r01's rows), beside their kernels
+        gk = [k for k in classes if k.startswith(pre)]
+        if gk:
+            gms, gn = sum(classes[k]["ms_total"] for k in gk), sum(classes[k]["launches"] for k in gk)
+            classes = {k: v for k, v in classes.items() if not k.startswith(pre)}
+            classes[cls] = {"ms_total": round(gms, 3), "launches": gn, "avg_ms": round(gms / gn, 4),
+                            "tflops": round(fl[cls] / (gms * 1e-3) / 1e12, 1)}
 
     # North-star leg (N = 1 only, after and outside the timed region): BASELINE C3 = 32 views x 518 x 518, camera-pose +
     # intrinsics priors, same weights; 1 warm-up + 3 timed steps + 1 HIP-event step for the cross-view attention class.
@@ -217,7 +228,7 @@ def main():
     if rank == 0:
         # the dominant KERNEL (largest total time among the instantiations timed separately); gemm_other mixes shapes, so it
         # is never the roofline row
-        dom = max((k for k in kernels if k != "gemm_other"), key=lambda k: kernels[k]["ms_total"])
+        dom = max((k for k in kernels if not k.endswith("_other")), key=lambda k: kernels[k]["ms_total"])
         ach = kernels[dom]["tflops"]
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # value is the committed rocprofv3 --pmc measurement of THIS workload (profiles/r01_traffic_n1.json), else null

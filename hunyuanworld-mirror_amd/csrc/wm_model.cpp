@@ -94,8 +94,9 @@ struct wm_handle {
   hipEvent_t camjoin = nullptr;
   // profiling
   bool prof = false;
-  std::vector<EvPair> ev[8];
-  size_t ev_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr int NKIND = 12;
+  std::vector<EvPair> ev[NKIND];
+  size_t ev_used[NKIND] = {};
 };
 
 namespace {
@@ -473,7 +474,7 @@ extern "C" void wm_destroy(wm_handle* h) {
   if (h->cstream) (void)hipStreamDestroy(h->cstream);
   if (h->cfork) (void)hipEventDestroy(h->cfork);
   if (h->cjoin) (void)hipEventDestroy(h->cjoin);
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < wm_handle::NKIND; ++k)
     for (auto& e : h->ev[k]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (h->comm.kind == 1 && h->comm.nccl) ncclCommDestroy(h->comm.nccl);
   delete h;
@@ -810,8 +811,10 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     memset(&a, 0, sizeof(a));
     a.Q = Q16; a.O = O16; a.H = heads; a.q_rows = M; a.q_head_stride = M; a.dtype = dt;
     static const bool force_gather = getenv("WM_FORCE_GATHER") != nullptr;  // 1-rank test of the collective path
-    // opt-in (WM_COMM_OVERLAP=1): a second active queue exposes the packed-fp32 hazard described at the DPT heads below
-    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return e && atoi(e) != 0; }();
+    // On by default for a sharded forward (WM_COMM_OVERLAP=0 / tuning comm_overlap = 0: gather on the compute queue).  The second
+    // queue is safe here: between fork and join the compute queue runs only the attention kernels, which contain no packed-fp32
+    // instruction (the hazard described at the DPT heads below needs one; tests/test_kernel_resources_cpu.py disassembles them)
+    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return !e || atoi(e) != 0; }();
     a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
     a.unit_flags = B<int>(h, "ATT_FLAGS");
     const bool sharded = is_global && (d.world > 1 || (force_gather && h->comm.kind != 0));
@@ -981,7 +984,11 @@ wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, cons
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = (int)w->shape[1]; a.Cout = (int)w->shape[0]; a.ksize = ks; a.stride = stride; a.pad = pad;
   a.Ho = (Hi + 2 * pad - ks) / stride + 1; a.Wo = (Wi + 2 * pad - ks) / stride + 1;
   a.relu_in = relu_in; a.resid_relu = resid_relu; a.relu_out = 0; a.dtype = c.hdt;
-  ProfScope ps(c.h, 3, c.s);
+  // timing kinds by kernel instantiation: the F -> F 3x3 convs of the two large pyramid levels, output_conv1 with its fused
+  // resize; everything else (small levels, 1x1, stride 2) under 3
+  const bool pyr = ks == 3 && stride == 1 && up_hs == 0 && a.Cin == a.Cout && a.Cin >= 128;
+  const int kind = up_hs > 0 ? 10 : pyr && Hi == 4 * c.d.gh ? 8 : pyr && Hi == 2 * c.d.gh ? 9 : 3;
+  ProfScope ps(c.h, kind, c.s);
   LCHK(c, wm_launch_conv(a, c.s));
   return WM_OK;
 }
@@ -1105,7 +1112,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       // ... with the head's tail (ReLU, 1x1 conv 32 -> C, activations) in its epilogue: the 32-channel tensor is never stored
       a.tail_w = F(h, sc + "output_conv2.2.weight"); a.tail_b = F(h, sc + "output_conv2.2.bias"); a.tail_C = out_dim; a.tail_act = act;
       a.tail_attr = out_attr + (size_t)v0 * Ho * Wo * (out_dim - 1); a.tail_conf = out_conf + (size_t)v0 * Ho * Wo;
-      ProfScope ps(h, 3, c.s);
+      ProfScope ps(h, 11, c.s);
       LCHK(c, wm_launch_conv3x3_n32_in16(a, c.s));
       tail_done = true;
     } else if (fuse_up2) {  // (the GS branch also needs the resized tensor itself: input_merger accumulates into it)
@@ -1160,7 +1167,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   if (!(h->plan_n == d.n && h->plan_nt == d.nt && h->plan_H == d.H && h->plan_W == d.W))
     return fail(h, WM_ERR_STATE, "no workspace for this shape: call wm_reserve(h, n_local, n_total, H, W) first (and again after loading weights)");
   wm_status st = WM_OK;
-  for (int k = 0; k < 8; ++k) h->ev_used[k] = 0;
+  for (int k = 0; k < wm_handle::NKIND; ++k) h->ev_used[k] = 0;
   ProfScope whole(h, 4, s);
   HIPCHK(h, hipMemsetAsync(B<char>(h, "ZERO256"), 0, 256, s));
   const int D = d.D;
@@ -1385,7 +1392,7 @@ extern "C" wm_status wm_profile_enable(wm_handle* h, int on) {
   return WM_OK;
 }
 extern "C" wm_status wm_profile_read(wm_handle* h, int kind, double* total_ms, int64_t* launches) {
-  if (!h || kind < 0 || kind > 7) return WM_ERR_INVALID;
+  if (!h || kind < 0 || kind >= wm_handle::NKIND) return WM_ERR_INVALID;
   double tot = 0;
   for (size_t i = 0; i < h->ev_used[kind]; ++i) {
     float ms = 0;
