@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256) void linear_f32_stream_kernel(const float* __r
 // 64-lane reduction per (row, column); here a wave owns 16 output columns, its lanes hold W[n0 + l%16][k .. k+3] and
 // X[l%16][k .. k+3] (k = kb + 4 (l/16)) straight from 16-B loads, and four v_mfma_f32_16x16x4_f32 per 16 k's do the
 // dot products — exact fp32 FMA chains, no cross-lane reduction; the KW waves of a block split K and meet in LDS.
-template <int KW>
+// U = 16-byte weight loads a lane keeps in flight (each with its X load): the kernel is latency-bound — a wave's whole life is
+// K / KW / 16 / U rounds of "request, wait, 4 U MFMAs" — so U sets the bytes in flight (2048 waves x U KiB over the chip):
+// U = 4 measured 1.9-3.1 TB/s of weight streaming, 8 / 16 bring the round count of every camera-head layer to 1 or 2.
+template <int KW, int U>
 __global__ __launch_bounds__(KW * 64) void linear_f32_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                   const float* __restrict__ b, float* __restrict__ Y, int M, int N,
                                                                   int K, int ldx, int ldy, int pre_act, int post_act,
@@ -157,15 +160,14 @@ __global__ __launch_bounds__(KW * 64) void linear_f32_mfma_kernel(const float* _
   const float* xp = X + (size_t)(lr < M ? lr : 0) * ldx + wave * kper + 4 * lk;
   const bool xok = lr < M;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int kb = 0; kb < kper; kb += 64) {  // 4 steps of 16 k's in flight
-    f32x4 wv[4], xv[4];
+  for (int kb = 0; kb < kper; kb += 16 * U) {  // U steps of 16 k's in flight
+    f32x4 wv[U], xv[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      wv[u] = *(const f32x4*)(wp + kb + 16 * u);
-      xv[u] = xok ? *(const f32x4*)(xp + kb + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int u = 0; u < U; ++u) wv[u] = __builtin_nontemporal_load((const f32x4*)(wp + kb + 16 * u));  // streamed once: keep X in the caches
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) xv[u] = xok ? *(const f32x4*)(xp + kb + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
       if (pre_act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) xv[u][e] = silu(xv[u][e]);
@@ -201,15 +203,18 @@ __global__ __launch_bounds__(64) void small_attention_kernel(const float* __rest
   const int D = heads * hd;
   const float* q = qkv + (size_t)i * 3 * D + head * hd;
   const float scale = 1.0f / sqrtf((float)hd);
+  // scores: the head dimension across the lanes, one wave reduction per key (S is the number of views: a handful; the former
+  // one-key-per-lane form ran 8 lanes through hd-long scalar dot products: 12 us at S = 8)
   float mx = -INFINITY;
-  for (int j = lane; j < S; j += 64) {
+  for (int j = 0; j < S; ++j) {
     const float* k = qkv + (size_t)j * 3 * D + D + head * hd;
-    float s = 0.f;
-    for (int d = 0; d < hd; ++d) s += q[d] * scale * k[d];
-    sc[j] = s;
-    mx = fmaxf(mx, s);
+    float part = 0.f;
+    for (int d = lane; d < hd; d += 64) part += q[d] * scale * k[d];
+    const float sj = wave_sum(part);
+    if (lane == (j & 63)) sc[j] = sj;
+    mx = fmaxf(mx, sj);   // wave-uniform
   }
-  mx = wave_max(mx);
+  __syncthreads();
   float sum = 0.f;
   for (int j = lane; j < S; j += 64) {
     const float e = expf(sc[j] - mx);
@@ -230,13 +235,43 @@ __global__ __launch_bounds__(64) void adaln_kernel(const float* __restrict__ tok
                                                    float* __restrict__ h, int D, float eps) {
   const int lane = threadIdx.x, row = blockIdx.x;
   const float* x = tok + (size_t)row * D;
+  const float* m = mod + (size_t)row * 3 * D;
+  if (D % 256 == 0 && D <= 2048) {  // the row in registers, 16-B accesses (D = 2048: 8 per lane)
+    float4 v[8];
+    const int nv = D / 256;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) { v[i] = *(const float4*)(x + (i * 64 + lane) * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    const float mean = wave_sum(s) / D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        ss += a * a + b * b + c * c + d * d;
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 sh = *(const float4*)(m + c), scl = *(const float4*)(m + D + c), g = *(const float4*)(m + 2 * D + c);
+        float4 o;
+        o.x = g.x * ((v[i].x - mean) * rstd * (1.0f + scl.x) + sh.x) + v[i].x;
+        o.y = g.y * ((v[i].y - mean) * rstd * (1.0f + scl.y) + sh.y) + v[i].y;
+        o.z = g.z * ((v[i].z - mean) * rstd * (1.0f + scl.z) + sh.z) + v[i].z;
+        o.w = g.w * ((v[i].w - mean) * rstd * (1.0f + scl.w) + sh.w) + v[i].w;
+        *(float4*)(h + (size_t)row * D + c) = o;
+      }
+    return;
+  }
   float s = 0.f;
   for (int c = lane; c < D; c += 64) s += x[c];
   const float mean = wave_sum(s) / D;
   float ss = 0.f;
   for (int c = lane; c < D; c += 64) { const float d = x[c] - mean; ss += d * d; }
   const float rstd = 1.0f / sqrtf(wave_sum(ss) / D + eps);
-  const float* m = mod + (size_t)row * 3 * D;
   for (int c = lane; c < D; c += 64) {
     const float ln = (x[c] - mean) * rstd;
     h[(size_t)row * D + c] = m[2 * D + c] * (ln * (1.0f + m[D + c]) + m[c]) + x[c];
@@ -293,9 +328,17 @@ hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, 
   if (M <= 16 && N % 16 == 0 && K % 1024 == 0 && wm_tuning[WM_TUNE_LIN_MFMA] != 0) {  // fp32-MFMA weight streaming
     // waves per block (they split K) chosen so that the launch has ~2000 waves: N / 16 blocks alone would leave the
     // 2048-column layers at 2 waves per CU
-    if (N <= 2048) hipLaunchKernelGGL((linear_f32_mfma_kernel<16>), dim3(N / 16), dim3(1024), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
-    else if (N <= 4096) hipLaunchKernelGGL((linear_f32_mfma_kernel<8>), dim3(N / 16), dim3(512), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
-    else hipLaunchKernelGGL((linear_f32_mfma_kernel<4>), dim3(N / 16), dim3(256), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate);
+#define WM_LINM(KW_, U_) hipLaunchKernelGGL((linear_f32_mfma_kernel<KW_, U_>), dim3(N / 16), dim3(KW_ * 64), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate)
+    // loads in flight per lane: as many as divide a wave's K share, capped by the registers a 16-wave block leaves (tuning lin_mfma = 4 | 8 | 16 forces the cap)
+    const int cap = wm_tuning[WM_TUNE_LIN_MFMA] >= 4 ? wm_tuning[WM_TUNE_LIN_MFMA] : 16;
+    if (N <= 2048) {
+      if ((K / 16) % 128 == 0 && cap >= 8) WM_LINM(16, 8); else WM_LINM(16, 4);
+    } else if (N <= 4096) {
+      if ((K / 8) % 256 == 0 && cap >= 16) WM_LINM(8, 16); else if ((K / 8) % 128 == 0 && cap >= 8) WM_LINM(8, 8); else WM_LINM(8, 4);
+    } else {
+      if ((K / 4) % 256 == 0 && cap >= 16) WM_LINM(4, 16); else if ((K / 4) % 128 == 0 && cap >= 8) WM_LINM(4, 8); else WM_LINM(4, 4);
+    }
+#undef WM_LINM
     return hipGetLastError();
   }
   if (K % 4 == 0 && K >= 256) {  // weight-streaming path

@@ -28,7 +28,7 @@ def read_all():
     for hw, d in NODES.items():
         for f, pth in d.items():
             try:
-                r[f"{os.path.basename(os.path.dirname(os.path.dirname(hw)))}:{f}"] = int(open(pth).read().strip())
+                r[f"{hw.split('/')[4]}:{f}"] = int(open(pth).read().strip())   # /sys/class/drm/cardN/...
             except Exception:
                 pass
     return r
@@ -70,7 +70,13 @@ def phase(name, launch, flops):
     for k in keys:
         v = [r[k] for r in rows if k in r]
         if v: agg[k] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v)}
-    print(json.dumps({"phase": name, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1) if flops else None, "samples": len(rows), "sysfs": agg, "rocm_smi": mid}), flush=True)
+    # the box's host shows every card of the node: ours is the one drawing the most power during the phase
+    cards = sorted({k.split(':')[0] for k in agg})
+    pw = {c: agg.get(f"{c}:power1_input", agg.get(f"{c}:power1_average", {"mean": 0}))["mean"] for c in cards}
+    mine = max(pw, key=pw.get) if pw else None
+    own = {k.split(':')[1]: {a: round(b / 1e6, 1) for a, b in v.items()} for k, v in agg.items() if mine and k.startswith(mine + ":")}
+    print(json.dumps({"phase": name, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1) if flops else None, "samples": len(rows),
+                      "card": mine, "W_or_MHz": own, "other_cards_mean_W": {c: round(v / 1e6) for c, v in pw.items() if c != mine}, "rocm_smi": mid}), flush=True)
 
 print(json.dumps({"nodes": {k: list(v) for k, v in NODES.items()}, "smi_idle": smi() if not NODES else None, "idle": read_all()}), flush=True)
 
