@@ -138,15 +138,16 @@ __global__ __launch_bounds__(256) void linear_f32_stream_kernel(const float* __r
   }
 }
 
-// Weight streaming on the fp32 MFMA (M <= 16 rows, N % 16 == 0, K % 64 == 0: every Linear of the camera trunk at up to
-// 16 views).  The VALU form above re-reads X for every pair of output columns (8 X loads per 2 W loads) and needs a
+// Weight streaming on the fp32 MFMA (M <= 64 rows, N % 16 == 0, K % (64 KW) == 0: every Linear of the camera trunk at up to
+// 64 views).  The VALU form above re-reads X for every pair of output columns (8 X loads per 2 W loads) and needs a
 // 64-lane reduction per (row, column); here a wave owns 16 output columns, its lanes hold W[n0 + l%16][k .. k+3] and
-// X[l%16][k .. k+3] (k = kb + 4 (l/16)) straight from 16-B loads, and four v_mfma_f32_16x16x4_f32 per 16 k's do the
-// dot products — exact fp32 FMA chains, no cross-lane reduction; the KW waves of a block split K and meet in LDS.
-// U = 16-byte weight loads a lane keeps in flight (each with its X load): the kernel is latency-bound — a wave's whole life is
-// K / KW / 16 / U rounds of "request, wait, 4 U MFMAs" — so U sets the bytes in flight (2048 waves x U KiB over the chip):
-// U = 4 measured 1.9-3.1 TB/s of weight streaming, 8 / 16 bring the round count of every camera-head layer to 1 or 2.
-template <int KW, int U>
+// X[16 t + l%16][k .. k+3] (k = kb + 4 (l/16)) straight from 16-B loads, and four v_mfma_f32_16x16x4_f32 per 16 k's and
+// 16-row tile t do the dot products — exact fp32 FMA chains, no cross-lane reduction; the KW waves of a block split K and
+// meet in LDS.  MT = row tiles (1, 2, 4): the weights are streamed once whatever M is (at 32 views the VALU kernel streamed
+// them at 0.5 TB/s: 130 us per layer, 7 ms of the C3 forward).  Four weight loads in flight per lane; 8 and 16 were
+// measured no faster (tools/bench_lin.py), so the limit is the access pattern (16 rows x 64 B per load instruction), not
+// the depth.
+template <int KW, int MT>
 __global__ __launch_bounds__(KW * 64) void linear_f32_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                   const float* __restrict__ b, float* __restrict__ Y, int M, int N,
                                                                   int K, int ldx, int ldy, int pre_act, int post_act,
@@ -155,42 +156,57 @@ __global__ __launch_bounds__(KW * 64) void linear_f32_mfma_kernel(const float* _
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16;
   const int lr = lane & 15, lk = lane >> 4;
-  const int kper = K / KW;  // K % (16 KW) == 0 (launcher)
+  const int kper = K / KW;  // K % (64 KW) == 0 (launcher)
   const float* wp = W + (size_t)(n0 + lr) * K + wave * kper + 4 * lk;
-  const float* xp = X + (size_t)(lr < M ? lr : 0) * ldx + wave * kper + 4 * lk;
-  const bool xok = lr < M;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int kb = 0; kb < kper; kb += 16 * U) {  // U steps of 16 k's in flight
-    f32x4 wv[U], xv[U];
+  const float* xp[MT];
+  bool xok[MT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) wv[u] = __builtin_nontemporal_load((const f32x4*)(wp + kb + 16 * u));  // streamed once: keep X in the caches
-#pragma unroll
-    for (int u = 0; u < U; ++u) xv[u] = xok ? *(const f32x4*)(xp + kb + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (pre_act == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[u][e] = silu(xv[u][e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][e], wv[u][e], acc, 0, 0, 0);
-    }
+  for (int t = 0; t < MT; ++t) {
+    xok[t] = 16 * t + lr < M;
+    xp[t] = X + (size_t)(xok[t] ? 16 * t + lr : 0) * ldx + wave * kper + 4 * lk;
   }
-  // D[row m = 4 lk + r][col n = lr]
+  f32x4 acc[MT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][(4 * lk + r) * 16 + lr] = acc[r];
-  __syncthreads();
-  if (tid < 256) {
-    const int m = tid >> 4, n = n0 + (tid & 15);
-    if (m < M) {
-      float v = b ? b[n] : 0.f;
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < kper; kb += 64) {  // 4 steps of 16 k's in flight
+    f32x4 wv[4], xv[MT][4];
 #pragma unroll
-      for (int w = 0; w < KW; ++w) v += red[w][tid];
-      if (post_act == 1) v = silu(v);
-      else if (post_act == 2) v = gelu_erf(v);
-      if (gamma) v *= gamma[n];
-      float* y = Y + (size_t)m * ldy + n;
-      *y = accumulate ? *y + v : v;
+    for (int u = 0; u < 4; ++u) wv[u] = *(const f32x4*)(wp + kb + 16 * u);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[t][u] = xok[t] ? *(const f32x4*)(xp[t] + kb + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (pre_act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[t][u][e] = silu(xv[t][u][e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t][u][e], wv[u][e], acc[t], 0, 0, 0);
+      }
+  }
+  // D[row m = 16 t + 4 lk + r][col n = lr]; one row tile at a time through the same LDS buffer
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    if (t) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * lk + r) * 16 + lr] = acc[t][r];
+    __syncthreads();
+    if (tid < 256) {
+      const int m = 16 * t + (tid >> 4), n = n0 + (tid & 15);
+      if (m < M) {
+        float v = b ? b[n] : 0.f;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) v += red[w][tid];
+        if (post_act == 1) v = silu(v);
+        else if (post_act == 2) v = gelu_erf(v);
+        if (gamma) v *= gamma[n];
+        float* y = Y + (size_t)m * ldy + n;
+        *y = accumulate ? *y + v : v;
+      }
     }
   }
 }
@@ -325,19 +341,15 @@ hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, 
                                 int ldy, int pre_act, int post_act, const float* gamma, int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0) return hipSuccess;
   if (ldx % 4) return hipErrorInvalidValue;
-  if (M <= 16 && N % 16 == 0 && K % 1024 == 0 && wm_tuning[WM_TUNE_LIN_MFMA] != 0) {  // fp32-MFMA weight streaming
+  if (M <= 64 && N % 16 == 0 && K % 1024 == 0 && wm_tuning[WM_TUNE_LIN_MFMA] != 0) {  // fp32-MFMA weight streaming
     // waves per block (they split K) chosen so that the launch has ~2000 waves: N / 16 blocks alone would leave the
-    // 2048-column layers at 2 waves per CU
-#define WM_LINM(KW_, U_) hipLaunchKernelGGL((linear_f32_mfma_kernel<KW_, U_>), dim3(N / 16), dim3(KW_ * 64), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate)
-    // loads in flight per lane: as many as divide a wave's K share, capped by the registers a 16-wave block leaves (tuning lin_mfma = 4 | 8 | 16 forces the cap)
-    const int cap = wm_tuning[WM_TUNE_LIN_MFMA] >= 4 ? wm_tuning[WM_TUNE_LIN_MFMA] : 16;
-    if (N <= 2048) {
-      if ((K / 16) % 128 == 0 && cap >= 8) WM_LINM(16, 8); else WM_LINM(16, 4);
-    } else if (N <= 4096) {
-      if ((K / 8) % 256 == 0 && cap >= 16) WM_LINM(8, 16); else if ((K / 8) % 128 == 0 && cap >= 8) WM_LINM(8, 8); else WM_LINM(8, 4);
-    } else {
-      if ((K / 4) % 256 == 0 && cap >= 16) WM_LINM(4, 16); else if ((K / 4) % 128 == 0 && cap >= 8) WM_LINM(4, 8); else WM_LINM(4, 4);
-    }
+    // 2048-column layers at 2 waves per CU; row tiles of 16 (M <= 16 / 32 / 64)
+#define WM_LINM(KW_, MT_) hipLaunchKernelGGL((linear_f32_mfma_kernel<KW_, MT_>), dim3(N / 16), dim3(KW_ * 64), 0, s, X, W, b, Y, M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate)
+#define WM_LINMT(KW_) do { if (M <= 16) WM_LINM(KW_, 1); else if (M <= 32) WM_LINM(KW_, 2); else WM_LINM(KW_, 4); } while (0)
+    if (N <= 2048) WM_LINMT(16);
+    else if (N <= 4096) WM_LINMT(8);
+    else WM_LINMT(4);
+#undef WM_LINMT
 #undef WM_LINM
     return hipGetLastError();
   }

@@ -143,6 +143,7 @@ struct WmConvArgs {
   // c < Cin/2 gets up_addx[ix][c], the others up_addy[iy][c - Cin/2]) without that tensor ever being stored.
   int up_hs, up_ws;
   const float* up_addx; const float* up_addy;
+  int dbg;             // timing experiments only (builds with -DWM_CONV_TIMING_EXPERIMENT; results are wrong): 1 no halo refill, 2 no epilogue, 4 no weight refill
 };
 bool wm_conv3x3_applicable(const WmConvArgs& a);
 // 3x3 / s1 / p1 conv with 32 output channels on a 16-bit NHWC input (conv_n32.hip); zero: >= 16 B of device zeros

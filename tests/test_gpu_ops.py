@@ -673,9 +673,12 @@ def test_bilinear(dev):
         assert _rel(y, ref) < 2e-6
 
 
-# the last four shapes take the fp32-MFMA weight-streaming kernel (M <= 16, N % 16 == 0, K % 1024 == 0): 4, 8 and 16 waves per block
+# from the third shape on: the fp32-MFMA weight-streaming kernel (M <= 64 in 1, 2 or 4 row tiles of 16, N % 16 == 0, K % 1024 == 0):
+# 4, 8 and 16 waves per block; (65, ...) falls back to the VALU streaming kernel
 @pytest.mark.parametrize("M,N,K,ldx", [(3, 256, 9, 12), (12, 512, 256, 256), (64, 6144, 2048, 2048), (5, 9, 1024, 1024),
-                                       (8, 6144, 2048, 2048), (13, 2048, 2048, 2080), (16, 4096, 1024, 1024), (1, 2048, 8192, 8192)])
+                                       (8, 6144, 2048, 2048), (13, 2048, 2048, 2080), (16, 4096, 1024, 1024), (1, 2048, 8192, 8192),
+                                       (32, 8192, 2048, 2048), (17, 2048, 2048, 2048), (40, 2048, 8192, 8192), (33, 4096, 1024, 1040),
+                                       (65, 2048, 2048, 2048)])
 def test_linear_f32(dev, M, N, K, ldx):
     g = torch.Generator().manual_seed(M + N)
     X = torch.zeros(M, ldx)
