@@ -571,57 +571,68 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
 #ifdef WM_CONV_TIMING_EXPERIMENT
   if ((p.dbg & 2) && acc[0][0][0] != 1.2345e-30f) return;
 #endif
-  // ---- epilogue: lane = pixel (lane & 31) of tile i, regs 4g..4g+3 <-> channels 8g + 4h + {0..3}.  The bias vectors depend
-  // on (j, g) only and are loaded once; the residual inputs of the next (i, j) group are requested before this group's
-  // stores (the compiler may not move a load across a possibly aliasing store: loads inside the innermost loop would pay
-  // an L2 / HBM round trip per 16-B store).
+  // ---- epilogue, through LDS.  The MFMA leaves lane (pixel = lane & 31, h = lane >> 5) with channels 8g + 4h + {0..3} of its
+  // pixel: stored from there, one instruction touches 32 pixels x 32 B = 32 cache lines (and the residual loads likewise); measured
+  // with the epilogue switched off (tools/conv_timing_experiment.py): 130 of the 330 us of an RCU conv2 at 148^2, i.e. 537 MB at
+  // 4.1 TB/s.  Here a wave parks one 32-pixel x (TN * 32)-channel group of accumulators in its own LDS slab (the main loop's
+  // buffers are dead) and reads it back row-major: 8 TN lanes cover one pixel's contiguous channels, an instruction covers
+  // 8 / TN whole pixels = 8 lines; bias, relu(resid), resid2 are added in that layout from equally coalesced loads, requested one
+  // group ahead.  Same values, same order of additions: bit-identical to the direct form.
+  constexpr int LP = TN * 8, PPI = 64 / LP, NI = 32 / PPI;  // lanes per pixel, pixels per instruction, instructions per group
+  constexpr int SROW = TN * 32 + 4;                         // slab row stride in floats (+16 B: rows start 4 banks apart)
+  static_assert(8 * 32 * SROW * 4 <= 2 * HALO_BYTES + 2 * B_BYTES, "epilogue slabs fit the main loop's LDS");
+  __syncthreads();                                          // every wave is done reading the halo / weight buffers
+  float* slab = (float*)smem + wave * 32 * SROW;
   const int h4 = (lane >> 5) * 4;
-  float4 bs[TN][4];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = n0 + (wn * TN + j) * 32 + h4 + 8 * g;
-      bs[j][g] = (p.bias && col < Cout) ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
-    }
-  float4 r1[2][4], r2[2][4];
-  auto group = [&](int ij, size_t& obase, int& cb) {  // -> pixel in range
-    const int i = ij / TN, j = ij - i * TN;
-    const int r = (wm * TM + i) * 32 + (lane & 31);
+  const int lp = lane % LP, pq = lane / LP;                 // this lane's 4-channel chunk and pixel-in-instruction (read-back layout)
+  const int cb = n0 + wn * TN * 32 + lp * 4;
+  const bool cok = cb < Cout;
+  const float4 bs = (p.bias && cok) ? *(const float4*)(p.bias + cb) : make_float4(0, 0, 0, 0);
+  constexpr int NS = NI >= 8 ? 2 : 1, NH = NI / NS;         // a group is read back in NS sub-steps of NH instructions (register budget)
+  float4 r1[2][NH], r2[2][NH];
+  auto pix = [&](int i, int k, size_t& obase) {  // pixel of tile row i handled by this lane in instruction k -> in range
+    const int r = (wm * TM + i) * 32 + k * PPI + pq;
     const int y = y0 + (r >> LGX), x = x0 + (r & (TPX - 1));
     obase = (((size_t)n * H + y) * W + x) * Cout;
-    cb = n0 + (wn * TN + j) * 32 + h4;
     return y < H && x < W;
   };
-  auto res_load = [&](int ij, float4 (&a)[4], float4 (&b)[4]) {
-    size_t obase; int cb;
-    const bool in = group(ij, obase, cb);
+  auto res_load = [&](int q, float4 (&a)[NH], float4 (&b)[NH]) {  // sub-step q = NS * i + half
+    const int i = q / NS, k0 = (q % NS) * NH;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = cb + 8 * g;
-      const bool ok = in && col < Cout;
-      a[g] = (p.resid && ok) ? *(const float4*)(p.resid + obase + col) : make_float4(0, 0, 0, 0);
-      b[g] = (p.resid2 && ok) ? *(const float4*)(p.resid2 + obase + col) : make_float4(0, 0, 0, 0);
+    for (int k = 0; k < NH; ++k) {
+      size_t obase;
+      const bool ok = pix(i, k0 + k, obase) && cok;
+      a[k] = (p.resid && ok) ? *(const float4*)(p.resid + obase + cb) : make_float4(0, 0, 0, 0);
+      b[k] = (p.resid2 && ok) ? *(const float4*)(p.resid2 + obase + cb) : make_float4(0, 0, 0, 0);
     }
   };
   res_load(0, r1[0], r2[0]);
 #pragma unroll
-  for (int ij = 0; ij < TM * TN; ++ij) {
-    if (ij + 1 < TM * TN) res_load(ij + 1, r1[(ij + 1) & 1], r2[(ij + 1) & 1]);
-    const int i = ij / TN, j = ij - i * TN;
-    size_t obase; int cb;
-    const bool in = group(ij, obase, cb);
+  for (int q = 0; q < TM * NS; ++q) {
+    const int i = q / NS, k0 = (q % NS) * NH;
+    if (q + 1 < TM * NS) res_load(q + 1, r1[(q + 1) & 1], r2[(q + 1) & 1]);
+    if (q % NS == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous group's read-back is complete (LDS is in order per wave; this pins the compiler)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = cb + 8 * g;
-      float4 v = make_float4(acc[i][j][4 * g] + bs[j][g].x, acc[i][j][4 * g + 1] + bs[j][g].y, acc[i][j][4 * g + 2] + bs[j][g].z, acc[i][j][4 * g + 3] + bs[j][g].w);
-      float4 rr = r1[ij & 1][g];
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(slab + (lane & 31) * SROW + j * 32 + 8 * g + h4) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const float4 a4 = *(const float4*)(slab + ((k0 + k) * PPI + pq) * SROW + lp * 4);
+      float4 v = make_float4(a4.x + bs.x, a4.y + bs.y, a4.z + bs.z, a4.w + bs.w);
+      float4 rr = r1[q & 1][k];
       if (p.resid_relu) rr = make_float4(fmaxf(rr.x, 0.f), fmaxf(rr.y, 0.f), fmaxf(rr.z, 0.f), fmaxf(rr.w, 0.f));
-      const float4 r2v = r2[ij & 1][g];
+      const float4 r2v = r2[q & 1][k];
       v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       v.x += r2v.x; v.y += r2v.y; v.z += r2v.z; v.w += r2v.w;
       if (p.relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      if (in && col < Cout) *(float4*)(p.y + obase + col) = v;
+      size_t obase;
+      if (pix(i, k0 + k, obase) && cok) *(float4*)(p.y + obase + cb) = v;
     }
   }
 }

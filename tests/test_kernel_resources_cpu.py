@@ -66,3 +66,26 @@ def test_attention_kernels_hold_no_packed_fp32_instruction(tmp_path):
         assert "v_mfma" in text, "not a device listing"
         hits = re.findall(r"v_pk_(?:mul|fma|add)_f32", text)
         assert not hits, f"{src}: {len(hits)} packed-fp32 instructions"
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_conv3x3_kernels_do_not_spill(tmp_path):
+    """The 256-pixel x 256-channel conv tile keeps 128 accumulator registers per lane and prefetches its residual inputs in the
+    epilogue: one float4 array too many and hipcc spills (a first form of the LDS-staged epilogue spilled 68 registers)."""
+    flags = None
+    for line in open(os.path.join(CSRC, "Makefile")):
+        if line.startswith("CXXFLAGS"):
+            flags = [f.replace("$(ARCH)", "gfx950") for f in line.split("=", 1)[1].split() if not f.startswith("$(")]
+    r = subprocess.run(["hipcc", *flags, "-x", "hip", "-c", os.path.join(CSRC, "conv3x3.hip"), "-o", str(tmp_path / "c.o"),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    n = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "conv3x3_rs_kernel" not in name:
+            continue
+        n += 1
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
+    assert n >= 8
