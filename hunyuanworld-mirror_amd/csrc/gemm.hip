@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -798,52 +798,37 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, ntiles = ntm * ntn;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  int band, nt;
+  tile_of(lid, ntm, ntn, p.group_bands, band, nt);
+  const int m0 = band * BM, n0 = nt * BN;
   const int l15 = lane & 15, lq = lane >> 4;
   const bool two = QI == 4 || wave < 4;  // this wave carries two A pieces per region (wave-uniform)
 
   // this wave's DMA pieces per K-tile, in issue order: A0 A0 B0 B0 | B1 B1 | A1 A1 (the second A piece only if `two`)
   const u16* gp[8];
   int loff[8];
-  auto piece = [&](int i, bool& isA) {  // index of this wave's piece i in its operand's 1-KiB piece list
-    isA = i < 2 || i >= 6;
-    const int half = (i >= 4) ? 1 : 0;              // A1 / B1
-    if (isA) {
-      const int cl = QI == 4 ? 2 * wave + (i & 1) : (wave < 4 ? 2 * wave + (i & 1) : 8 + (wave - 4));  // index in the 2*APC-piece region
-      return (cl < APC ? cl : cl - APC + 2 * APC) + APC * half;   // rows wr' * WROWS + 8 * APC * qm + ...
-    }
-    const int cl = 2 * wave + (i & 1);
-    return (cl >> 2) * 8 + (cl & 3) + 4 * half;                   // cols wc' * 64 + 32 qn + ...
-  };
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    bool isA;
-    const int pl = piece(i, isA);
+    const bool isA = i < 2 || i >= 6;
+    const int half = (i >= 4) ? 1 : 0;              // A1 / B1
+    int pl;
+    if (isA) {
+      const int cl = QI == 4 ? 2 * wave + (i & 1) : (wave < 4 ? 2 * wave + (i & 1) : 8 + (wave - 4));  // index in the 2*APC-piece region
+      pl = (cl < APC ? cl : cl - APC + 2 * APC) + APC * half;   // rows wr' * WROWS + 8 * APC * qm + ...
+    } else {
+      const int cl = 2 * wave + (i & 1);
+      pl = (cl >> 2) * 8 + (cl & 3) + 4 * half;                 // cols wc' * 64 + 32 qn + ...
+    }
+    const int r = pl * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int gr = (DBG == 4 ? 0 : (isA ? m0 : n0)) + r;
+    const int lim = (isA ? p.M : p.N) - 1;
+    gr = gr < lim ? gr : lim;
+    gp[i] = (isA ? (const u16*)p.A + (size_t)gr * p.lda : (const u16*)p.W + (size_t)gr * p.ldw) + c * 8;
     loff[i] = (isA ? 0 : A_BYTES) + pl * 1024;
   }
-  // Persistent over tiles: block b walks tiles b, b + gridDim.x, ... (gridDim.x a multiple of 8 whenever it is smaller than the
-  // tile count, so a block's tiles stay on its XCD's contiguous range of xcd_remap).  One tile per block = the former launch.
-  // (the per-lane row / chunk of a piece is recomputed per tile rather than kept: 16 registers across the epilogue)
-  int m0, n0;
-  auto setup_tile = [&](int tile) {
-    const int lid = xcd_remap(tile, ntiles);
-    int band, nt;
-    tile_of(lid, ntm, ntn, p.group_bands, band, nt);
-    m0 = band * BM; n0 = nt * BN;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      bool isA;
-      const int pl = piece(i, isA);
-      const int r = pl * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      int gr = (DBG == 4 ? 0 : (isA ? m0 : n0)) + r;
-      const int lim = (isA ? p.M : p.N) - 1;
-      gr = gr < lim ? gr : lim;
-      gp[i] = (isA ? (const u16*)p.A + (size_t)gr * p.lda : (const u16*)p.W + (size_t)gr * p.ldw) + c * 8;
-    }
-  };
-  int tile = blockIdx.x;
-  setup_tile(tile);
   auto dma = [&](int buf, int i0, int i1) {
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
@@ -861,11 +846,17 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   const int a_base = wr * WROWS * 128, b_base = A_BYTES + wc * 64 * 128;
 
   f32x4 acc[SM][SN];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int j = 0; j < SN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   s16x8 a[QI][2], b0[2][2], b1[2][2];
 
   const int nk = p.K / 64;
   dma(0, 0, 8);
-  if (nk > 1) dma(1, 0, 8);
+  if (nk > 1) { dma(1, 0, 8); WM_W2(12, 9); } else WM_W2(4, 3);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
 
   auto stage_end = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -879,16 +870,6 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
     __builtin_amdgcn_s_barrier();
   };
 
-  for (;;) {  // ---- one output tile per iteration; its first two K-tiles were requested before the previous tile's epilogue
-  // (the counts below are exact for the first tile; for later ones the previous epilogue's stores are also in flight, YOUNGER
-  // than these pieces: in-order completion makes the same immediates a stronger wait, never a weaker one)
-  if (nk > 1) WM_W2(12, 9); else WM_W2(4, 3);
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int i = 0; i < SM; ++i)
-#pragma unroll
-    for (int j = 0; j < SN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
     const char* tile = smem + buf * STAGE;
@@ -954,28 +935,10 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
         for (int j = 0; j < 2; ++j) acc[QI + i][j] = mfma16<T>(b0[j][kh], a[i][kh], acc[QI + i][j]);
     mfma_end();
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // both wave groups are past their last LDS read (phase 3 runs from registers)
-  const int em = m0 + wr * WROWS, en = n0 + wc * 64;
-  tile += gridDim.x;
-  const bool more = tile < ntiles;             // block-uniform
-  // next tile's K-tiles 0 and 1 fly under this tile's epilogue — except where the epilogue needs the registers (the fused qkv
-  // epilogue on the 256-row tile spills with the eight source pointers live across it): there they are requested after it
-  constexpr bool PRE = !(EPI == WM_EPI_QKV && QI == 4);
-  if (PRE && more) {
-    setup_tile(tile);
-    dma(0, 0, 8);
-    if (nk > 1) dma(1, 0, 8);
-  }
-  if (!(DBG == 5 && acc[0][0][0] != 1.2345e-30f))  // (timing experiment: no epilogue)
-    epilogue16<T, EPI, SM, SN>(p, acc, em, en, lane);
-  if (!more) break;
-  if (!PRE) {
-    setup_tile(tile);
-    dma(0, 0, 8);
-    if (nk > 1) dma(1, 0, 8);
-  }
-  }
 #undef WM_W2
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  if (DBG == 5 && acc[0][0][0] != 1.2345e-30f) return;  // timing experiment: no epilogue
+  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wr * WROWS, n0 + wc * 64, lane);
 }
 
 template <int T, int EPI, int DBG = 0, int QI = 4>
@@ -988,11 +951,7 @@ hipError_t launch_pp2(const WmGemmArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<T, EPI, 1, DBG, QI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
-  // persistent blocks once the tiles outnumber the CUs (one 128-KiB block per CU): gemm_persist = 0 launches one block per tile
-  static const int ncu8 = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); const int n = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; return n / 8 * 8; }();
-  const int ntiles = ntm * ntn;
-  const int grid = (wm_tuning[WM_TUNE_GEMM_PERSIST] != 0 && ntiles > ncu8 && ncu8 > 0) ? ncu8 : ntiles;
-  hipLaunchKernelGGL((gemm_pp2_kernel<T, EPI, 1, DBG, QI>), dim3(grid), dim3(512), shm, s, a);
+  hipLaunchKernelGGL((gemm_pp2_kernel<T, EPI, 1, DBG, QI>), dim3(ntm * ntn), dim3(512), shm, s, a);
   return hipGetLastError();
 }
 
