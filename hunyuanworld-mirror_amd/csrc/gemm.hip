@@ -1073,7 +1073,7 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
   if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
   const int cfg = pick_cfg(a);
-  const int gb = wm_tuning[WM_TUNE_GEMM_GROUP] >= 0 ? wm_tuning[WM_TUNE_GEMM_GROUP] : 4;
+  const int gb = wm_tuning[WM_TUNE_GEMM_GROUP] >= 0 ? wm_tuning[WM_TUNE_GEMM_GROUP] : 6;  // row bands per supertile: 6 measured 2-3 % ahead of 4 / 8 at 32 views, equal at 8 (tools/bench_gemm_group.py)
   if (a.epi == WM_EPI_QKV) {
     if (a.qkv.tokens_per_view <= 0 || a.qkv.grid_w <= 0 || a.M >= (1 << 20) || a.qkv.tokens_per_view >= (1 << 16)) return hipErrorInvalidValue;
     WmGemmArgs b = a;
