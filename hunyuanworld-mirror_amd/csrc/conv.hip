@@ -207,6 +207,14 @@ template <int T>
 hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   const bool narrow = a.Cout <= 32;
   if (a.Cin % 64 == 0) {
+    // 128 x 128 tiles that do not cover the chip (the stride-2 conv of the deepest DPT level: 184 blocks of 4 waves, each a
+    // 144-step K loop waiting ~1 us of memory latency per 0.25 us of MFMA work: 232 us = 235 TF/s): 64-pixel tiles double the
+    // blocks, two or three of which share a CU and overlap each other's waits
+    static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    const long M = (long)a.N * a.Ho * a.Wo;
+    const long t128 = ((M + 127) / 128) * ((a.Cout + 127) / 128);
+    static const int bm_env = [] { const char* e = getenv("WM_CONV_BM"); return e ? atoi(e) : 0; }();
+    if (!narrow && (bm_env == 64 || (bm_env == 0 && t128 < ncu))) return launch_cfg<T, 64, 2, 2, 1, 2>(a, s);
     return narrow ? launch_cfg<T, 64, 4, 1, 1, 1>(a, s) : launch_cfg<T, 64, 2, 2, 2, 2>(a, s);
   } else {
     return narrow ? launch_cfg<T, 32, 4, 1, 1, 1>(a, s) : launch_cfg<T, 32, 2, 2, 2, 2>(a, s);
