@@ -34,9 +34,10 @@ if __name__ == "__main__":
             rows.append((D[k][0] / nfwd / 1e6, k, D[k][1] / nfwd, f / 1e6, w / 1e6, us, (f + w) / us / 1e6))
     rows.sort(reverse=True)
     out = ["| ms / forward | kernel | blocks x threads | launches / forward | HBM read MB / launch | HBM write MB / launch | us / launch | achieved HBM TB/s |", "|---|---|---|---|---|---|---|---|"]
-    for r in rows[:26]:
+    keep = rows[:36] + [r for r in rows[36:] if "im2col" in r[1][0] or "attn" in r[1][0]]
+    for r in keep:
         out.append(f"| {r[0]:.2f} | `{r[1][0]}` | {r[1][1]} threads | {r[2]:.0f} | {r[3]:.1f} | {r[4]:.1f} | {r[5]:.1f} | {r[6]:.2f} |")
     text = "\n".join(out)
     print(text)
     if len(sys.argv) > 4:
-        open(sys.argv[4], "w").write("# HBM traffic and achieved bandwidth by kernel (8 x 518^2 bf16, N = 1)\n\nrocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (FETCH_SIZE doubled: gfx950 reports half of wide coalesced reads) joined with the\n`--kernel-trace` durations of the same command (`python bench.py --steps 1|3 --warmup 1 --no-cpu-baseline`); HBM peak 8 TB/s.\nThe MFMA-bound kernels (GEMM, attention, conv) sit far below it by design; the HBM-bound ones (LayerNorm, bilinear, combine, copies) are the ones to read against the peak.\n\n" + text + "\n")
+        open(sys.argv[4], "w").write("# HBM traffic and achieved bandwidth by kernel (8 x 518^2 bf16, N = 1)\n\nrocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (FETCH_SIZE doubled: gfx950 reports half of wide coalesced reads) joined with the\n`--kernel-trace` durations of the same command (`python3 bench.py --steps 1|3 --warmup 1 --no-cpu-baseline --no-north-star`); HBM peak 8 TB/s.\nThe MFMA-bound kernels (GEMM, attention, conv) sit far below it by design; the HBM-bound ones (LayerNorm, bilinear, combine, copies) are the ones to read against the peak.\n\n" + text + "\n")
