@@ -1,6 +1,6 @@
 """Precompute the rounding-emulated oracle outputs for the benchmark-size fixtures (tests/golden/emu_<name>.npz).
 
-    python oracle/gen_emulated.py [name ...]
+    python oracle/gen_emulated.py [--f16] [name ...]
 
 Uses only this repository's own code (oracle/worldmirror_ref.py in emulate=("bf16", "f16") mode + the name-keyed synthetic
 weights): no reference import, so it can run anywhere; it is precomputed only because the CPU oracle needs minutes at
@@ -25,7 +25,7 @@ from conftest import GOLD, golden_preset, load_golden, torch_weights  # noqa: E4
 from oracle import worldmirror_ref as R  # noqa: E402
 from test_gpu_emulated import PERTURB, perturbed  # noqa: E402  (one definition of the perturbation for script and test)
 
-DEFAULT = ["full_8v_518_noprior", "full_4v_518_pose_ray", "refinit_full_8v_518_noprior"]
+DEFAULT = ["full_8v_518_noprior", "full_4v_518_pose_ray", "refinit_full_8v_518_noprior", "full_2v_518_allpriors"]
 
 
 def run(name: str, emulate=("bf16", "f16")):
@@ -49,7 +49,7 @@ def run(name: str, emulate=("bf16", "f16")):
                 v = v[:, :, ::sub, ::sub]
             store[tag + k] = np.ascontiguousarray(v)
         del o
-    path = os.path.join(GOLD, "emu_" + name + ".npz")
+    path = os.path.join(GOLD, ("emu_" if emulate[0] == "bf16" else "emu_" + emulate[0] + "_") + name + ".npz")
     np.savez_compressed(path, **store)
     def rl(a, b):
         return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
@@ -59,5 +59,7 @@ def run(name: str, emulate=("bf16", "f16")):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or DEFAULT):
-        run(n)
+    args = [a for a in sys.argv[1:] if a != "--f16"]
+    f16 = "--f16" in sys.argv[1:]   # backbone operands in f16 (BASELINE config 5's dtype): tests/golden/emu_f16_<name>.npz
+    for n in (args or DEFAULT):
+        run(n, ("f16", "f16") if f16 else ("bf16", "f16"))

@@ -121,7 +121,16 @@ def make_inputs(seed: int, S: int, H: int, W: int, priors: bool):
     return views
 
 
-def make_inputs_518(seed: int, S: int, H: int, W: int, priors: bool):
+def make_depth_518(seed: int, S: int, H: int, W: int):
+    """Depth prior of a benchmark-size fixture, regenerated from its seed like the image (tests/conftest.py draws it the same way):
+    depths in [0.5, 4.5), 5 % of the pixels invalid (0)."""
+    g = torch.Generator().manual_seed(seed)
+    d = 0.5 + 4.0 * torch.rand(1, S, H, W, generator=g)
+    d[torch.rand(1, S, H, W, generator=g) < 0.05] = 0.0
+    return d.numpy()
+
+
+def make_inputs_518(seed: int, S: int, H: int, W: int, priors: bool, depth: bool = False):
     """Benchmark-size inputs.  The image is NOT stored in the fixture (25 MB at 8 views): it is regenerated from the
     seed exactly as bench.py draws it (torch.rand on a seeded CPU generator) and checked against a stored fp64 sum.
     Priors (C3 flag set: camera pose + intrinsics) are small and stored."""
@@ -134,18 +143,24 @@ def make_inputs_518(seed: int, S: int, H: int, W: int, priors: bool):
         K[..., 0, :] *= W / 14.0
         K[..., 1, :] *= H / 14.0
         views["camera_intrinsics"] = K.astype(np.float32)
+    if depth:
+        views["depthmap"] = make_depth_518(seed + 7, S, H, W)
     return views
 
 
 def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="sensitive", splat_stride=1, regen_img=False):
     if regen_img:
-        views_np = make_inputs_518(seed, S, H, W, priors=sum(flags) > 0)
+        views_np = make_inputs_518(seed, S, H, W, priors=sum(flags) > 0, depth=bool(flags[1]))
     else:
         views_np = make_inputs(seed, S, H, W, priors=sum(flags) > 0)
     views = {k: torch.from_numpy(v.copy()) for k, v in views_np.items()}
-    store = {f"in_{k}": v for k, v in views_np.items() if not (regen_img and k == "img")}
+    store = {f"in_{k}": v for k, v in views_np.items() if not (regen_img and k in ("img", "depthmap"))}
     if regen_img:
-        store["regen_img"] = np.array(__import__("json").dumps({"kind": "torch_rand", "seed": seed, "shape": [1, S, 3, H, W]}))
+        spec = {"kind": "torch_rand", "seed": seed, "shape": [1, S, 3, H, W]}
+        if "depthmap" in views_np:
+            spec["depth_seed"] = seed + 7
+            store["sum_in_depthmap"] = np.array(views_np["depthmap"].astype(np.float64).sum())
+        store["regen_img"] = np.array(__import__("json").dumps(spec))
         store["sum_in_img"] = np.array(views_np["img"].astype(np.float64).sum())
     store["cond_flags"] = np.array(flags, np.int64)
     store["cfg_json"] = np.array(__import__("json").dumps(cfg.to_dict()))
@@ -224,13 +239,15 @@ def main():
     if a.full_518:
         cfg = WMConfig()
         want = set(a.cases.split(",")) if a.cases else None
-        todo = [c for c in ("full_8v_518_noprior", "full_4v_518_pose_ray") if want is None or c in want]
+        todo = [c for c in ("full_8v_518_noprior", "full_4v_518_pose_ray", "full_2v_518_allpriors") if want is None or c in want]
         if todo:
             m = build_reference(cfg)
             if "full_8v_518_noprior" in todo:
                 run_case(m, cfg, "full_8v_518_noprior", 1234, 8, 518, 518, [0, 0, 0], sub=8, keep_taps=False, regen_img=True)
             if "full_4v_518_pose_ray" in todo:
                 run_case(m, cfg, "full_4v_518_pose_ray", 4321, 4, 518, 518, [1, 0, 1], sub=8, keep_taps=False, regen_img=True)
+            if "full_2v_518_allpriors" in todo:  # depth prior at the benchmarked size (PatchEmbed_Mlp on 37 x 37 patches of the normalised depth)
+                run_case(m, cfg, "full_2v_518_allpriors", 777, 2, 518, 518, [1, 1, 1], sub=8, keep_taps=False, regen_img=True)
             del m
         if want is None or "refinit_full_8v_518_noprior" in want:
             m = build_reference(cfg, "refinit")

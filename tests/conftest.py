@@ -32,6 +32,14 @@ def load_golden(name):
         img = torch.rand(*g["shape"], generator=gen).numpy()
         assert abs(float(img.astype(np.float64).sum()) - float(z["sum_in_img"])) < 1e-6 * img.size, "regenerated image differs from the fixture's"
         views["img"] = img
+        if "depth_seed" in g:  # depth prior drawn as oracle/gen_golden.py make_depth_518 draws it
+            gd = torch.Generator().manual_seed(int(g["depth_seed"]))
+            S, H, W = g["shape"][1], g["shape"][3], g["shape"][4]
+            dep = 0.5 + 4.0 * torch.rand(1, S, H, W, generator=gd)
+            dep[torch.rand(1, S, H, W, generator=gd) < 0.05] = 0.0
+            dep = dep.numpy()
+            assert abs(float(dep.astype(np.float64).sum()) - float(z["sum_in_depthmap"])) < 1e-6 * dep.size, "regenerated depth prior differs from the fixture's"
+            views["depthmap"] = dep
     outs = {k[4:]: v for k, v in z.items() if k.startswith("out_")}
     return cfg, views, [int(x) for x in z["cond_flags"]], outs, z
 

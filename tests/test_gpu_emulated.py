@@ -146,30 +146,32 @@ def test_gpu_vs_emulated_oracle_bf16_heads():
     _check("tiny_3v_70x56_pose_ray [bf16 heads]", got, emu, pert, outs, 1, views["img"].shape[-2])
 
 
-def _emu_518(name, cfg, views, flags, preset, sub):
-    """(emulated, emulated on the perturbed input) at every sub-th pixel, from tests/golden/emu_<name>.npz or live"""
-    path = os.path.join(GOLD, "emu_" + name + ".npz")
+def _emu_518(name, cfg, views, flags, preset, sub, dtype="bf16"):
+    """(emulated, emulated on the perturbed input) at every sub-th pixel, from tests/golden/emu_<name>.npz (emu_f16_<name>.npz for an
+    f16 backbone) or live"""
+    path = os.path.join(GOLD, ("emu_" if dtype == "bf16" else "emu_" + dtype + "_") + name + ".npz")
     H = views["img"].shape[-2]
     if os.environ.get("WM_EMU_LIVE"):
-        e, q = _emulated(cfg, views, flags, preset), _emulated(cfg, perturbed(views), flags, preset)
+        e, q = _emulated(cfg, views, flags, preset, dtype=dtype), _emulated(cfg, perturbed(views), flags, preset, dtype=dtype)
         return {k: _sub(v, sub, H) for k, v in e.items()}, {k: _sub(v, sub, H) for k, v in q.items()}
     if not os.path.exists(path):
         return None, None
     z = dict(np.load(path, allow_pickle=False))
     if "perturb" not in z:
         return None, None
-    assert str(z["emulate"]) == "bf16,f16" and str(z["weights_preset"]) == preset and float(z["perturb"]) == PERTURB
+    assert str(z["emulate"]) == dtype + ",f16" and str(z["weights_preset"]) == preset and float(z["perturb"]) == PERTURB
     return ({k[4:]: v for k, v in z.items() if k.startswith("out_")}, {k[5:]: v for k, v in z.items() if k.startswith("pert_")})
 
 
-@pytest.mark.parametrize("name", ["full_8v_518_noprior", "full_4v_518_pose_ray", "refinit_full_8v_518_noprior"])
+@pytest.mark.parametrize("name", ["full_8v_518_noprior", "full_4v_518_pose_ray", "refinit_full_8v_518_noprior", "full_2v_518_allpriors"])
 def test_518_golden_and_emulated(name):
     """The benchmarked size.  BASELINE C2's own inputs (bench.py: 8 x 518 x 518, seed 1234, no priors) on both weight presets
     and 4 x 518 x 518 with camera-pose + intrinsics priors (the C3 flag set), against the reference's outputs
     (oracle/gen_golden.py --full-518: every 8th pixel + fp64 checksums of the full tensors) and the emulated oracle.
     Only at 518 x 518 is pos_embed used verbatim (vision_transformer.py:179-180), are the DPT levels 148 / 296 / 518
     (dense_head.py:217-251) with 518 not a multiple of the conv tile, and do the 32 x 8-pixel conv tile, the fused 148 -> 296
-    resize, the DMA-fed 32-channel conv with the tail in its epilogue and the attention tail split run end to end."""
+    resize, the DMA-fed 32-channel conv with the tail in its epilogue and the attention tail split run end to end.
+    full_2v_518_allpriors adds the depth prior at this size (PatchEmbed_Mlp over 37 x 37 patches of the normalised depth map)."""
     if not os.path.exists(os.path.join(GOLD, name + ".npz")):
         pytest.skip("fixture missing")
     cfg, views, flags, outs, z = load_golden(name)
@@ -182,3 +184,17 @@ def test_518_golden_and_emulated(name):
         s, ref = float(got[k].astype(np.float64).sum()), float(z["sum_" + k])
         lim = 5e-3 if k == "normals" else 2e-3  # signed sums: the components of unit normals cancel heavily
         assert abs(s - ref) / abs(ref) < lim, (k, s, ref)
+
+
+def test_518_f16_backbone_all_priors():
+    """BASELINE config 5's dtype (f16 backbone operands) at the benchmarked size, all three priors on: the general attention kernel
+    (the pipelined no-max kernel is bf16-only), f16 GEMM epilogues and the depth-prior encoder at 518 x 518, against the reference
+    and the f16-emulating oracle (oracle/gen_emulated.py --f16)."""
+    name = "full_2v_518_allpriors"
+    if not os.path.exists(os.path.join(GOLD, name + ".npz")):
+        pytest.skip("fixture missing")
+    cfg, views, flags, outs, z = load_golden(name)
+    sub, H = int(z["subsample"]), views["img"].shape[-2]
+    got = _gpu(cfg, views, flags, "sensitive", dtype="f16")
+    emu, pert = _emu_518(name, cfg, views, flags, "sensitive", sub, dtype="f16")
+    _check(name + " [f16]", got, emu, pert, outs, sub, H)

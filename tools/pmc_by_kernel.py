@@ -29,6 +29,7 @@ if __name__ == "__main__":
     nfwd = sum(1 for r in tr if "im2col_kernel" in r["Kernel_Name"]) or 1
     rows = []
     for k in F:
+        if "__amd_rocclr" in k[0]: continue   # the runtime's copy kernels: the weight upload at start-up, not part of a forward
         if k in D and k in W:
             f, w, us = 2 * F[k][0] / F[k][1] * 1024, W[k][0] / W[k][1] * 1024, D[k][0] / D[k][1] / 1e3
             rows.append((D[k][0] / nfwd / 1e6, k, D[k][1] / nfwd, f / 1e6, w / 1e6, us, (f + w) / us / 1e6))
