@@ -169,7 +169,12 @@ def run_case(m, cfg, name, seed, S, H, W, flags, sub=1, keep_taps=True, preset="
         if sum(flags) > 0:
             pri = m.extract_priors(views)
             for nm, pr_ in zip(("prior_depths", "prior_rays", "prior_poses"), pri):
-                if pr_ is not None:
+                if pr_ is None:
+                    continue
+                if regen_img and nm == "prior_depths":  # benchmark size: every 8th pixel + the fp64 sum of the whole map
+                    store["prior_depths_sub8"] = np.ascontiguousarray(pr_.numpy()[..., ::8, ::8])
+                    store["sum_prior_depths"] = np.array(pr_.double().sum().item())
+                else:
                     store[nm] = pr_.numpy()
             taps, psi = m.visual_geometry_transformer(views["img"], pri, cond_flags=flags)
         else:

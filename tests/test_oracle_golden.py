@@ -53,6 +53,21 @@ def test_oracle_priors_match_reference():
     assert rel_l2(p.numpy(), z["prior_poses"]) < 1e-6
 
 
+def test_oracle_priors_match_reference_at_518():
+    """extract_priors at the benchmarked size (depth prior of full_2v_518_allpriors, regenerated from its seed): the reference's
+    normalised depth map at every 8th pixel and its fp64 sum over all pixels; rays and poses in full."""
+    import os
+    from conftest import GOLD
+    if not os.path.exists(os.path.join(GOLD, "full_2v_518_allpriors.npz")):
+        pytest.skip("fixture missing")
+    cfg, views, flags, outs, z = load_golden("full_2v_518_allpriors")
+    d, r, p = R.extract_priors({k: torch.from_numpy(v) for k, v in views.items()})
+    assert rel_l2(d.numpy()[..., ::8, ::8], z["prior_depths_sub8"]) < 1e-6
+    assert abs(float(d.double().sum()) - float(z["sum_prior_depths"])) < 1e-6 * abs(float(z["sum_prior_depths"]))
+    assert rel_l2(r.numpy(), z["prior_rays"]) < 1e-6
+    assert rel_l2(p.numpy(), z["prior_poses"]) < 1e-6
+
+
 def test_oracle_gs_branch_matches_reference():
     cfg, o, outs, z, col = _run("tiny_gs_2v_70x70")
     for k, v in outs.items():
