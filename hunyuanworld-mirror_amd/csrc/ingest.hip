@@ -90,3 +90,5 @@ hipError_t wm_launch_resample_v_tensor(const unsigned char* tmp, float* out, int
                      bounds, kk, ksize);
   return hipGetLastError();
 }
+
+#include "wm_end.h"

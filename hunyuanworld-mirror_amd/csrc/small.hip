@@ -403,3 +403,5 @@ hipError_t wm_launch_cam_update(float* pred, const float* delta, float* out, int
   hipLaunchKernelGGL(cam_update_kernel, dim3((S * 9 + 255) / 256), dim3(256), 0, s, pred, delta, out, S * 9, first);
   return hipGetLastError();
 }
+
+#include "wm_end.h"

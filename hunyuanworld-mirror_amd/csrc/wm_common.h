@@ -134,3 +134,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     hipError_t _e = (expr);                                                           \
     if (_e != hipSuccess) return wm_fail(hipGetErrorString(_e), __FILE__, __LINE__);  \
   } while (0)
+
+// No packed-fp32 VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in this translation unit's device code: with
+// two or more HIP queues active such an instruction can lose a half result (profiles/r02_multiqueue_hazard.md), and the
+// forward runs the DPT heads, the camera head and the sharded K/V all-gather on their own queues.  The one translation unit
+// that opts out (WM_ALLOW_PACKED_FP32: gemm.hip, for the GELU epilogue of fc1) runs only in the single-queue backbone;
+// tests/test_kernel_resources_cpu.py disassembles every object and holds the line.  Closed by wm_end.h (last include).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WM_ALLOW_PACKED_FP32)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#define WM_PK_GUARD 1
+#endif
