@@ -1246,14 +1246,18 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
     }
   }
 
-  // One queue by default.  WM_HEADS_CONCURRENT=1 forks the camera head and the DPT heads onto the handle's own queues (-1.7 ms per
-  // forward at 8 x 518^2) — OPT-IN, because kernels of DIFFERENT kinds sharing a SIMD expose a packed-fp32 hazard on this
-  // toolchain / chip: with >= 2 queues active, a compiler-generated v_pk_mul_f32 / v_pk_fma_f32 (op_sel forms) occasionally drops one
-  // half's result in 16-lane groups (inputs read correctly, one fma term missing; never with one queue; gone when the kernel is
-  // built without SLP-packed fp32).  Reproduced WITHOUT torch on the ROCm 7.2 runtime with the library's own kernels:
-  // tools/micro/splat_hazard_repro.cpp, profiles/r02_multiqueue_hazard.md.  All kernels are therefore built -fno-slp-vectorize, and
-  // the product path keeps one queue unless asked.
-  static const bool conc_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return e && atoi(e) != 0; }();
+  // The camera head and the DPT heads are independent of each other: each runs on one of the handle's own queues, forked from and
+  // joined back to the caller's stream (-0.8 ms per forward at 8 x 518^2: the HBM-bound camera head and the under-filled small DPT
+  // levels run beside the MFMA-bound convs).  WM_HEADS_CONCURRENT=0 (tuning heads_concurrent = 0) keeps one queue.
+  // History: round 1 saw sparse wrong lanes with several queues active and fenced this off; round 2 traced it to packed-fp32 VALU
+  // instructions (compiler-generated v_pk_mul_f32 / v_pk_fma_f32, op_sel forms) dropping one half's result in 16-lane groups when a
+  // kernel of another kind shares the SIMD from another queue — reproduced without torch on the ROCm 7.2 runtime with the library's own
+  // kernels (tools/micro/splat_hazard_repro.cpp, profiles/r02_multiqueue_hazard.md), never with one queue, never without packed fp32.
+  // Every device function outside gemm.hip is now compiled with the packed-fp32 feature off (wm_common.h; checked on the generated
+  // code by tests/test_kernel_resources_cpu.py), and the only kernels that keep packed fp32 — the GELU GEMMs of the backbone — have
+  // finished before this fork.  tools/stress_concurrent_heads.py: 1 900 concurrent forwards (C2, C3, C5 flag set) bit-identical
+  // to the serial one.
+  static const bool conc_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return !e || atoi(e) != 0; }();
   const bool serial = !(wm_tuning[WM_TUNE_HEADS_CONC] >= 0 ? wm_tuning[WM_TUNE_HEADS_CONC] != 0 : conc_env) || h->prof;
   if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
   if (!serial) LCHK(c, hipEventRecord(h->hfork, s));
