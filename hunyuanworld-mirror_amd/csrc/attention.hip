@@ -793,5 +793,3 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (qb == 4) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3>(a, s) : launch<WM_T_F16, 4, 1, 3>(a, s);
   return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 2>(a, s) : launch<WM_T_F16, 4, 1, 2>(a, s);
 }
-
-#include "wm_end.h"

@@ -437,5 +437,3 @@ hipError_t wm_launch_attention_v3(const WmAttnArgs& a, int grid, int* flags, int
   else hipLaunchKernelGGL((attn_v3_kernel<1, false>), dim3(grid), dim3(256), 0, s, a, flags);
   return hipGetLastError();
 }
-
-#include "wm_end.h"

@@ -239,5 +239,3 @@ hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, s) : launch_T<WM_T_F16>(a, s);
 }
-
-#include "wm_end.h"

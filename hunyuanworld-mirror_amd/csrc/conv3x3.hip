@@ -712,5 +712,3 @@ hipError_t wm_launch_conv3x3(const WmConvArgs& a_in, hipStream_t s) {
 #endif
   return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, s) : launch_T<WM_T_F16>(a, s);
 }
-
-#include "wm_end.h"

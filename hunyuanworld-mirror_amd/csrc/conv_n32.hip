@@ -207,5 +207,3 @@ hipError_t wm_launch_conv3x3_n32_in16(const WmConvN32Args& a, hipStream_t s) {
   }
   return hipGetLastError();
 }
-
-#include "wm_end.h"

@@ -647,5 +647,3 @@ hipError_t wm_launch_dpt_tail(const float* y32, const float* w, const float* b, 
   hipLaunchKernelGGL(dpt_tail_kernel, dim3(grid_for(npix)), dim3(256), 0, s, y32, w, b, attr, conf, npix, C, act);
   return hipGetLastError();
 }
-
-#include "wm_end.h"

@@ -14,7 +14,6 @@
 //    tiles stay in flight across the barrier (guides "Pipelining across barriers", T3+T4);
 //  * the MFMA is issued as D = W_frag * A_frag (operands swapped), so a lane owns one output ROW
 //    and 4 consecutive COLUMNS per register group: the epilogue reads/writes float4 (16 B/lane).
-#define WM_ALLOW_PACKED_FP32  // the GELU epilogue (fc1) is written in packed fp32; these kernels run in the single-queue backbone only (wm_common.h)
 #include "wm_common.h"
 #include "wm_kernels.h"
 
@@ -1087,5 +1086,3 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   c.group_bands = gb;
   return c.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(c, cfg, s) : launch_T<WM_T_F16>(c, cfg, s);
 }
-
-#include "wm_end.h"

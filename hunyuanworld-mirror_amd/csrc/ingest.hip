@@ -90,5 +90,3 @@ hipError_t wm_launch_resample_v_tensor(const unsigned char* tmp, float* out, int
                      bounds, kk, ksize);
   return hipGetLastError();
 }
-
-#include "wm_end.h"

@@ -295,5 +295,3 @@ hipError_t wm_launch_rasterize(const WmRasterArgs& a, hipStream_t s, unsigned lo
                      th, a.width, a.height, a.out_rgb, a.out_depth, a.out_alpha);
   return hipGetLastError();
 }
-
-#include "wm_end.h"

@@ -171,5 +171,3 @@ hipError_t wm_launch_confidence_mask(const float* conf, size_t n, unsigned int K
   hipLaunchKernelGGL(sel_mask_kernel, dim3(nblk), dim3(256), 0, s, conf, n, (const SelState*)st, (const unsigned int*)blk_eq, mask);
   return hipGetLastError();
 }
-
-#include "wm_end.h"

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void small_attention_kernel(const float* __rest
 }
 
 // camera_head.py:84-88: h = gate * (LN_noaffine(tok) * (1 + scale) + shift) + tok ; one wave per row
-__global__ __launch_bounds__(64) void adaln_kernel(const float* __restrict__ tok, const float* __restrict__ mod,
+WM_NO_PACKED_FP32 __global__ __launch_bounds__(64) void adaln_kernel(const float* __restrict__ tok, const float* __restrict__ mod,
                                                    float* __restrict__ h, int D, float eps) {
   const int lane = threadIdx.x, row = blockIdx.x;
   const float* x = tok + (size_t)row * D;
@@ -403,5 +403,3 @@ hipError_t wm_launch_cam_update(float* pred, const float* delta, float* out, int
   hipLaunchKernelGGL(cam_update_kernel, dim3((S * 9 + 255) / 256), dim3(256), 0, s, pred, delta, out, S * 9, first);
   return hipGetLastError();
 }
-
-#include "wm_end.h"

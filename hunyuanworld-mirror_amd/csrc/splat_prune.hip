@@ -153,5 +153,3 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
   if (K_out) *K_out = (int)K;
   return hipGetLastError();
 }
-
-#include "wm_end.h"

@@ -2,6 +2,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// Packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) are kept out of every kernel except the GELU GEMM
+// instantiations of gemm.hip: with two or more HIP queues active such an instruction can lose a half result
+// (profiles/r02_multiqueue_hazard.md), and the forward runs the DPT heads, the camera head and the sharded K/V all-gather on their own
+// queues.  How: the build's -fno-slp-vectorize removes the compiler-formed ones; WM_NO_PACKED_FP32 on a function removes what is left
+// where vector-typed source still packs (a whole-translation-unit attribute was tried: it also doubled the v_mov_b32 count of the
+// conv kernels, -13 % on the 148^2 convs); tests/test_kernel_resources_cpu.py compiles every object to assembly and holds the line.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WM_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define WM_NO_PACKED_FP32
+#endif
 
 typedef unsigned short u16;
 typedef __attribute__((ext_vector_type(8))) short s16x8;     // 8 x 16-bit MFMA A/B fragment
@@ -135,12 +146,3 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     if (_e != hipSuccess) return wm_fail(hipGetErrorString(_e), __FILE__, __LINE__);  \
   } while (0)
 
-// No packed-fp32 VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in this translation unit's device code: with
-// two or more HIP queues active such an instruction can lose a half result (profiles/r02_multiqueue_hazard.md), and the
-// forward runs the DPT heads, the camera head and the sharded K/V all-gather on their own queues.  The one translation unit
-// that opts out (WM_ALLOW_PACKED_FP32: gemm.hip, for the GELU epilogue of fc1) runs only in the single-queue backbone;
-// tests/test_kernel_resources_cpu.py disassembles every object and holds the line.  Closed by wm_end.h (last include).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(WM_ALLOW_PACKED_FP32)
-#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
-#define WM_PK_GUARD 1
-#endif

@@ -50,9 +50,9 @@ def test_no_packed_fp32_instruction_outside_the_gelu_gemm(tmp_path):
     """With two or more HIP queues active a packed-fp32 VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) can lose a
     half result (profiles/r02_multiqueue_hazard.md).  The forward uses extra queues in two places — the DPT heads + camera head
     beside each other, and the sharded K/V all-gather under the local attention (wm_model.cpp) — so no kernel that can run there may
-    hold one.  Held by construction (wm_common.h: target attribute no-packed-fp32-ops on every device function; gemm.hip opts out
-    for the GELU epilogue of fc1, which runs in the single-queue backbone) and checked here on the generated code: every object
-    is compiled to assembly and scanned per kernel; only the EPI = 2 (GELU) instantiations of gemm.hip may contain packed fp32."""
+    hold one.  The build's -fno-slp-vectorize removes the compiler-formed ones and WM_NO_PACKED_FP32 (wm_common.h) the rest where
+    vector-typed source still packs; this test is what holds the line: every object is compiled to assembly and scanned per kernel,
+    and only the EPI = 2 (GELU) instantiations of gemm.hip — fc1 of the single-queue backbone — may contain packed fp32."""
     flags = None
     for line in open(os.path.join(CSRC, "Makefile")):
         if line.startswith("CXXFLAGS"):
