@@ -104,6 +104,33 @@ def gemm_case(M, N, K, epi):
         assert L.wm_op_gemm(0, epi, p(A), p(W), p(Cc), p(bias), None, M, N, K, s) == 0
     return run, 2.0 * M * N * K, (A, W, Cc, bias)
 
+def tuned(mk, **kv):
+    def make():
+        run, fl, keep = mk()
+        def run2():
+            for k, v in kv.items(): L.wm_set_tuning(k.encode(), v)
+            run()
+            for k in kv: L.wm_set_tuning(k.encode(), -1)
+        return run2, fl, keep
+    return make
+
+PHASES = [("attention_v3_32v", lambda: attn_case(32 * 1376, 7)), ("attention_general_32v", lambda: attn_case(32 * 1376, 3)),
+          ("attention_v3_8v", lambda: attn_case(8 * 1376, 7)), ("gemm_fc1_8v_gelu", lambda: gemm_case(8 * 1376, 4096, 1024, 2)),
+          ("gemm_fc1_32v_gelu", lambda: gemm_case(32 * 1376, 4096, 1024, 2))]
+if os.environ.get("MFMA_SHAPES"):   # energy per flop of the two MFMA shapes: the lock-step GEMM kernels exist in both
+    PHASES = [("gemm_fc1_32v pingpong 16x16x32", lambda: gemm_case(32 * 1376, 4096, 1024, 1)),
+              ("gemm_fc1_32v lockstep 32x32x16", tuned(lambda: gemm_case(32 * 1376, 4096, 1024, 1), gemm_pp=0, gemm_mfma16=0, gemm_cfg=4)),
+              ("gemm_fc1_32v lockstep 16x16x32", tuned(lambda: gemm_case(32 * 1376, 4096, 1024, 1), gemm_pp=0, gemm_mfma16=2, gemm_cfg=4)),
+              ("gemm_4096^3 pingpong 16x16x32", lambda: gemm_case(4096, 4096, 4096, 1)),
+              ("gemm_4096^3 lockstep 32x32x16", tuned(lambda: gemm_case(4096, 4096, 4096, 1), gemm_pp=0, gemm_mfma16=0, gemm_cfg=4)),
+              ("gemm_4096^3 lockstep 16x16x32", tuned(lambda: gemm_case(4096, 4096, 4096, 1), gemm_pp=0, gemm_mfma16=2, gemm_cfg=4))]
+for name, mk in PHASES:
+    run, fl, keep = mk()
+    phase(name, run, fl)
+    del keep
+    time.sleep(1.0)
+L.wm_set_tuning(b"attn_qb", -1)
+raise SystemExit(0)
 for name, mk in (("attention_v3_32v", lambda: attn_case(32 * 1376, 7)), ("attention_general_32v", lambda: attn_case(32 * 1376, 3)),
                  ("attention_v3_8v", lambda: attn_case(8 * 1376, 7)), ("gemm_fc1_8v_gelu", lambda: gemm_case(8 * 1376, 4096, 1024, 2)),
                  ("gemm_fc1_32v_gelu", lambda: gemm_case(32 * 1376, 4096, 1024, 2))):
