@@ -130,12 +130,3 @@ for name, mk in PHASES:
     del keep
     time.sleep(1.0)
 L.wm_set_tuning(b"attn_qb", -1)
-raise SystemExit(0)
-for name, mk in (("attention_v3_32v", lambda: attn_case(32 * 1376, 7)), ("attention_general_32v", lambda: attn_case(32 * 1376, 3)),
-                 ("attention_v3_8v", lambda: attn_case(8 * 1376, 7)), ("gemm_fc1_8v_gelu", lambda: gemm_case(8 * 1376, 4096, 1024, 2)),
-                 ("gemm_fc1_32v_gelu", lambda: gemm_case(32 * 1376, 4096, 1024, 2))):
-    run, fl, keep = mk()
-    phase(name, run, fl)
-    del keep
-    time.sleep(1.0)
-L.wm_set_tuning(b"attn_qb", -1)
