@@ -1255,7 +1255,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   // kernels (tools/micro/splat_hazard_repro.cpp, profiles/r02_multiqueue_hazard.md), never with one queue, never without packed fp32.
   // No kernel outside the GELU instantiations of gemm.hip contains a packed-fp32 instruction any more (-fno-slp-vectorize,
   // WM_NO_PACKED_FP32 in wm_common.h; held by tests/test_kernel_resources_cpu.py, which disassembles every object), and those
-  // GELU GEMMs of the backbone have finished before this fork.  tools/stress_concurrent_heads.py: 1 900 concurrent forwards (C2, C3, C5 flag set) bit-identical
+  // GELU GEMMs of the backbone have finished before this fork.  tools/stress_concurrent_heads.py: 4 900 concurrent forwards (C2, C3, C5 flag set) bit-identical
   // to the serial one.
   static const bool conc_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return !e || atoi(e) != 0; }();
   const bool serial = !(wm_tuning[WM_TUNE_HEADS_CONC] >= 0 ? wm_tuning[WM_TUNE_HEADS_CONC] != 0 : conc_env) || h->prof;

@@ -51,7 +51,7 @@ def test_c2_single_queue_forward_is_bit_identical_to_the_default(model_and_out):
     """The default forward runs the camera head and the DPT heads on the handle's own queues; WM_HEADS_CONCURRENT=0 (here: the tuning
     key) keeps everything on the caller's stream.  Same kernels, same order within a head: the outputs must be bit-identical, and the
     concurrent forward must repeat itself bit for bit (the packed-fp32 multi-queue hazard of profiles/r02_multiqueue_hazard.md is
-    excluded by construction: tests/test_kernel_resources_cpu.py; tools/stress_concurrent_heads.py ran 1 900 forwards)."""
+    excluded by construction: tests/test_kernel_resources_cpu.py; tools/stress_concurrent_heads.py ran 4 900 forwards)."""
     from hunyuanworld_mirror_amd import _lib
     m, img, out = model_and_out
     L = _lib.lib()
