@@ -1247,7 +1247,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   }
 
   // The camera head and the DPT heads are independent of each other: each runs on one of the handle's own queues, forked from and
-  // joined back to the caller's stream (-0.8 ms per forward at 8 x 518^2: the HBM-bound camera head and the under-filled small DPT
+  // joined back to the caller's stream (-1.15 ms per forward at 8 x 518^2, -5 ms at 32 views: the HBM-bound camera head and the under-filled small DPT
   // levels run beside the MFMA-bound convs).  WM_HEADS_CONCURRENT=0 (tuning heads_concurrent = 0) keeps one queue.
   // History: round 1 saw sparse wrong lanes with several queues active and fenced this off; round 2 traced it to packed-fp32 VALU
   // instructions (compiler-generated v_pk_mul_f32 / v_pk_fma_f32, op_sel forms) dropping one half's result in 16-lane groups when a
