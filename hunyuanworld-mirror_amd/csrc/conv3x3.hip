@@ -632,7 +632,16 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
       v.x += r2v.x; v.y += r2v.y; v.z += r2v.z; v.w += r2v.w;
       if (p.relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       size_t obase;
-      if (pix(i, k0 + k, obase) && cok) *(float4*)(p.y + obase + cb) = v;
+      if (pix(i, k0 + k, obase) && cok) {
+        if (p.out16) {  // block-uniform: 16-bit output only (8 B per lane, 128 B per pixel and instruction)
+          uint2 u;
+          u.x = (uint32_t)f2t<T>(v.x) | ((uint32_t)f2t<T>(v.y) << 16);
+          u.y = (uint32_t)f2t<T>(v.z) | ((uint32_t)f2t<T>(v.w) << 16);
+          *(uint2*)((u16*)p.y + obase + cb) = u;
+        } else {
+          *(float4*)(p.y + obase + cb) = v;
+        }
+      }
     }
   }
 }
@@ -665,17 +674,28 @@ hipError_t launch_cfg(const WmConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+int cu_count() {
+  static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+  return ncu;
+}
+int pick_bn(const WmConvArgs& a) {  // output-channel tile (see launch_T)
+  const int ncu = cu_count();
+  const long ptiles = (long)a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP);
+  int bn = a.Cout > 128 ? 256 : a.Cout > 64 ? 128 : a.Cout > 32 ? 64 : 32;
+  while (bn > 64 && 2 * ptiles * ((a.Cout + bn - 1) / bn) < ncu) bn >>= 1;
+  if (wm_tuning[WM_TUNE_CONV_BN] > 0) bn = wm_tuning[WM_TUNE_CONV_BN];
+  return bn;
+}
+
 template <int T>
 hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   // output-channel tile: as wide as Cout allows, but narrower while the launch would cover less than half the chip
   // (the 19^2 and 37^2 DPT levels: 32 / 72 pixel tiles; measured with tools/bench_conv.py: 37^2 161 -> 249 TF/s at
   // 128 channels, 19^2 46 -> 112 at 64; 74^2 with 200 tiles stays fastest at 256) — the halo is then re-staged per
   // channel tile, from L2.  conv_bn (tuning) forces a width.
-  static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+  static const int ncu = cu_count();
   const long ptiles = (long)a.N * ((a.Hi + TP - 1) / TP) * ((a.Wi + TP - 1) / TP);
-  int bn = a.Cout > 128 ? 256 : a.Cout > 64 ? 128 : a.Cout > 32 ? 64 : 32;
-  while (bn > 64 && 2 * ptiles * ((a.Cout + bn - 1) / bn) < ncu) bn >>= 1;
-  if (wm_tuning[WM_TUNE_CONV_BN] > 0) bn = wm_tuning[WM_TUNE_CONV_BN];
+  const int bn = pick_bn(a);
   const bool rs_ok = (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0;
   const bool rs = rs_ok && a.up_hs == 0;  // register-staged main loop (plain input, even chunk count)
   if (rs_ok && a.up_hs > 0 && bn == 128) {  // fused resize, 128-channel tile
@@ -699,6 +719,10 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+bool wm_conv3x3_out16_ok(const WmConvArgs& a) {  // exactly the launches launch_T sends to conv3x3_rs_kernel with a plain input
+  return wm_conv3x3_applicable(a) && a.up_hs == 0 && (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0 && pick_bn(a) >= 128;
+}
+
 bool wm_conv3x3_applicable(const WmConvArgs& a) {
   return a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 64 == 0 && a.Cout % 4 == 0 && a.Hi * a.Wi >= 256;
 }
@@ -710,5 +734,6 @@ hipError_t wm_launch_conv3x3(const WmConvArgs& a_in, hipStream_t s) {
 #else
   a.dbg = 0;
 #endif
+  if (a.out16 && !wm_conv3x3_out16_ok(a)) return hipErrorInvalidValue;
   return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, s) : launch_T<WM_T_F16>(a, s);
 }

@@ -143,9 +143,12 @@ struct WmConvArgs {
   // c < Cin/2 gets up_addx[ix][c], the others up_addy[iy][c - Cin/2]) without that tensor ever being stored.
   int up_hs, up_ws;
   const float* up_addx; const float* up_addy;
+  int out16;           // y is a 16-bit NHWC tensor of the conv's operand type (f16 / bf16) and no fp32 is written: for outputs whose only consumer
+                       // rounds them to that type anyway (x2 -> out_conv).  Register-staged 3x3 kernel only: ask wm_conv3x3_out16_ok first
   int dbg;             // timing experiments only (builds with -DWM_CONV_TIMING_EXPERIMENT; results are wrong): 1 no halo refill, 2 no epilogue, 4 no weight refill
 };
 bool wm_conv3x3_applicable(const WmConvArgs& a);
+bool wm_conv3x3_out16_ok(const WmConvArgs& a);   // the launch would take a kernel that implements out16
 // 3x3 / s1 / p1 conv with 32 output channels on a 16-bit NHWC input (conv_n32.hip); zero: >= 16 B of device zeros
 struct WmConvN32Args {
   const uint16_t* x; const uint16_t* w; const float* bias; float* y; const uint16_t* zero;

@@ -753,13 +753,13 @@ struct Ctx {
   } while (0)
 
 wm_status gemm(Ctx& c, int dt, int epi, const void* A, int lda, const void* Wp, int ldw, void* C, int ldc, const float* bias,
-               const float* gamma, int M, int N, int K, WmGemmArgs* extra = nullptr) {
+               const float* gamma, int M, int N, int K, WmGemmArgs* extra = nullptr, int prof_kind = -1) {
   WmGemmArgs a;
   if (extra) a = *extra; else memset(&a, 0, sizeof(a));
   a.A = A; a.W = Wp; a.C = C; a.bias = bias; a.gamma = gamma;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.dtype = dt; a.epi = epi;
   // timing kinds by kernel instantiation: the three epilogues that carry the transformer blocks, the rest under 2
-  ProfScope ps(c.h, epi == WM_EPI_QKV ? 5 : epi == WM_EPI_RESID ? 6 : epi == WM_EPI_GELU_T16 ? 7 : 2, c.s);
+  ProfScope ps(c.h, prof_kind >= 0 ? prof_kind : epi == WM_EPI_QKV ? 5 : epi == WM_EPI_RESID ? 6 : epi == WM_EPI_GELU_T16 ? 7 : 2, c.s);
   LCHK(c, wm_launch_gemm(a, c.s));
   return WM_OK;
 }
@@ -974,7 +974,7 @@ wm_status camera_head(Ctx& c, float* out_params) {
 // (+ position tables), fused into the 3x3 halo kernel's input staging.
 wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, const float* resid, bool resid_relu, const float* resid2,
                float* y, int N, int Hi, int Wi, int ks, int stride, int pad, bool relu_in, int up_hs = 0, int up_ws = 0,
-               const float* up_addx = nullptr, const float* up_addy = nullptr) {
+               const float* up_addx = nullptr, const float* up_addy = nullptr, bool* out16 = nullptr) {
   const Weight* w = W(c.h, wname + ".weight");
   if (!w || !w->w16) return fail(c.h, WM_ERR_STATE, "missing conv weight " + wname);
   WmConvArgs a;
@@ -984,6 +984,11 @@ wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, cons
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = (int)w->shape[1]; a.Cout = (int)w->shape[0]; a.ksize = ks; a.stride = stride; a.pad = pad;
   a.Ho = (Hi + 2 * pad - ks) / stride + 1; a.Wo = (Wi + 2 * pad - ks) / stride + 1;
   a.relu_in = relu_in; a.resid_relu = resid_relu; a.relu_out = 0; a.dtype = c.hdt;
+  if (out16) {  // the caller can take y as a 16-bit tensor (its only consumer rounds it to the operand type anyway): granted when the kernel can
+    static const int o16_env = [] { const char* e = getenv("WM_OUTCONV_GEMM"); return e ? atoi(e) : 1; }();
+    *out16 = o16_env != 0 && wm_conv3x3_out16_ok(a);
+    a.out16 = *out16 ? 1 : 0;
+  }
   // timing kinds by kernel instantiation: the F -> F 3x3 convs of the two large pyramid levels, output_conv1 with its fused
   // resize; everything else (small levels, 1x1, stride 2) under 3
   const bool pyr = ks == 3 && stride == 1 && up_hs == 0 && a.Cin == a.Cout && a.Cin >= 128;
@@ -994,10 +999,20 @@ wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, cons
 }
 
 // ResidualConvUnit (dense_head.py:435-455): y = conv2(relu(conv1(relu x))) + relu(x) (+ extra)
-wm_status rcu(Ctx& c, const std::string& p, const float* x, const float* extra, float* tmp, float* y, int N, int Hh, int Ww) {
+// y16: when non-null the caller can take y as a 16-bit tensor; *y16 tells whether it got one
+wm_status rcu(Ctx& c, const std::string& p, const float* x, const float* extra, float* tmp, float* y, int N, int Hh, int Ww, bool* y16 = nullptr) {
   wm_status st = conv(c, x, p + "conv1", true, nullptr, false, nullptr, tmp, N, Hh, Ww, 3, 1, 1, true);
   if (st) return st;
-  return conv(c, tmp, p + "conv2", true, x, true, extra, y, N, Hh, Ww, 3, 1, 1, true);
+  return conv(c, tmp, p + "conv2", true, x, true, extra, y, N, Hh, Ww, 3, 1, 1, true, 0, 0, nullptr, nullptr, y16);
+}
+
+// FeatureFusionBlock.out_conv (1x1, dense_head.py:496) on x2 [N*H*W][F]: a plain GEMM when x2 came as a 16-bit tensor (the ping-pong
+// kernel, fp32 NHWC out), the generic conv kernel on the fp32 tensor otherwise
+wm_status out_conv(Ctx& c, const std::string& name, const float* x2, bool x2_is_16, float* y, int N, int Hh, int Ww, int F_) {
+  if (!x2_is_16) return conv(c, x2, name, true, nullptr, false, nullptr, y, N, Hh, Ww, 1, 1, 0, false);
+  const Weight* w = W(c.h, name + ".weight");
+  if (!w || !w->w16 || (int)w->shape[0] != F_ || (int)w->shape[1] != F_) return fail(c.h, WM_ERR_STATE, "missing conv weight " + name);
+  return gemm(c, c.hdt, WM_EPI_F32, x2, F_, w->w16, F_, y, F_, F(c.h, name + ".bias"), nullptr, N * Hh * Ww, F_, F_, nullptr, 3);
 }
 
 // DPTHead (dense_head.py:107-295) for views [v0, v0+n) of this rank
@@ -1054,11 +1069,12 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       if (st) return st;
     }
     // refinenet4: RCU2(rn4) -> resize to level 3 -> out_conv
-    st = rcu(c, sc + "refinenet4.resConfUnit2.", rn[3], nullptr, S0, S1, n, Hs[3], Ws[3]);
+    bool x16 = false;
+    st = rcu(c, sc + "refinenet4.resConfUnit2.", rn[3], nullptr, S0, S1, n, Hs[3], Ws[3], &x16);
     if (st) return st;
     // out_conv (1x1) and the align_corners bilinear resize are both linear and the interpolation weights sum
     // to 1, so out_conv(resize(x)) == resize(out_conv(x)): run the 1x1 at the LOW resolution (4x fewer FLOPs)
-    st = conv(c, S1, sc + "refinenet4.out_conv", true, nullptr, false, nullptr, S0, n, Hs[3], Ws[3], 1, 1, 0, false);
+    st = out_conv(c, sc + "refinenet4.out_conv", S1, x16, S0, n, Hs[3], Ws[3], F_);
     if (st) return st;
     LCHK(c, wm_launch_bilinear(S0, S2, n, Hs[3], Ws[3], Hs[2], Ws[2], F_, nullptr, nullptr, c.s));
     float* cur = S2;  // output of the previous fusion block at level L
@@ -1075,10 +1091,10 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       st = rcu(c, rp + "resConfUnit1.", rn[L], cur, others[0], others[1], n, Hs[L], Ws[L]);
       if (st) return st;
       // x = RCU2(x)
-      st = rcu(c, rp + "resConfUnit2.", others[1], nullptr, others[0], others[2], n, Hs[L], Ws[L]);
+      st = rcu(c, rp + "resConfUnit2.", others[1], nullptr, others[0], others[2], n, Hs[L], Ws[L], &x16);
       if (st) return st;
       const int Ho = L > 0 ? Hs[L - 1] : 2 * Hs[0], Wo = L > 0 ? Ws[L - 1] : 2 * Ws[0];
-      st = conv(c, others[2], rp + "out_conv", true, nullptr, false, nullptr, others[0], n, Hs[L], Ws[L], 1, 1, 0, false);
+      st = out_conv(c, rp + "out_conv", others[2], x16, others[0], n, Hs[L], Ws[L], F_);
       if (st) return st;
       if (L == 0 && fuse_up1) { cur = others[0]; break; }  // the last resize is fused into output_conv1's input staging
       LCHK(c, wm_launch_bilinear(others[0], others[1], n, Hs[L], Ws[L], Ho, Wo, F_, nullptr, nullptr, c.s));
