@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--cpu-views", type=int, default=8, help="views of the CPU-baseline sample (8 = the C2 workload itself)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the C3 (32 views, priors) leg that follows the timed region at N = 1")
     ap.add_argument("--tiny", action="store_true", help="scaled-down architecture (plumbing check only)")
+    ap.add_argument("--gs", action="store_true", help="3D-Gaussian head on (BASELINE config C5's flag set with --dtype f16; rasterisation not run, voxel merge off)")
     a = ap.parse_args()
 
     from hunyuanworld_mirror_amd import WorldMirror, WMConfig
@@ -126,12 +127,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg = WMConfig.tiny() if a.tiny else WMConfig()
+    cfg = WMConfig.tiny() if a.tiny else WMConfig(enable_gs=True) if a.gs else WMConfig()
     H = W = a.size if not a.tiny else 70
     n_local, n_total = a.views_per_gpu, a.views_per_gpu * world
     torch.set_num_threads(host_cores())
     log("generating + uploading weights")
     m = WorldMirror(arch=cfg, dtype=a.dtype).to(dev).init_synthetic_weights()
+    if a.gs:
+        m.enable_prune = False   # the cross-view voxel merge is a caller's step (rasterization.py:301), not part of the forward's heads
     log("weights ready")
     if world > 1:
         m.shard()
@@ -179,7 +182,7 @@ def main():
     m.profile(True)
     m(views, flags)
     torch.cuda.synchronize(dev)
-    fl = flop_model(cfg, n_local, n_total, H, W)
+    fl = flop_model(cfg, n_local, n_total, H, W, heads=4 if a.gs else 3)
     classes = {}
     for k, name in KINDS.items():
         ms, n = m.profile_read(k)
@@ -250,7 +253,7 @@ def main():
         line = {"metric": "views/sec", "value": round(n_total / (ms_step * 1e-3), 3), "unit": "views/s", "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-                "config": {"workload": f"{n_total}-view {H}x{W} {a.dtype}, {'camera-pose + intrinsics priors' if a.priors else 'no priors'}, camera+depth+pointmap+normal heads, "
+                "config": {"workload": f"{n_total}-view {H}x{W} {a.dtype}, {'camera-pose + intrinsics priors' if a.priors else 'no priors'}, camera+depth+pointmap+normal" + ("+gaussian" if a.gs else "") + " heads, "
                                        f"{n_local} views/GPU" + (", tiny arch" if a.tiny else ", full 1.23B-param arch"),
                            "views_per_gpu": n_local, "global_views": n_total, "parallelism": f"view-shard x{world}",
                            "collective": (f"RCCL all-gather of K|V per global layer, world {m._comm[1]}" if m._comm else "none (1 GPU)")},
