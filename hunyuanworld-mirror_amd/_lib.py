@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (loads libamdhip64.so.7 / librccl.so.1 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwm_hip.so")
+# WM_HIP_LIB: a diagnostic build of the same library (tools only, e.g. the in-kernel stamp build of csrc/Makefile "stamps")
+LIB_PATH = os.environ.get("WM_HIP_LIB") or os.path.join(_HERE, "libwm_hip.so")
 
 WM_DT = {"bf16": 0, "f16": 1, "fp16": 1, "float16": 1, "bfloat16": 0}
 EPI_F32, EPI_T16, EPI_GELU_T16, EPI_RESID = 0, 1, 2, 3

@@ -684,7 +684,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const WmAttnArgs p, i
 }
 
 template <int T, int NW, int QB, int MINW, int LZ = 1, int STG = 1>
-hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
+hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, int fast = 0) {   // fast: 0 general kernel only, 3 attn_v3 first, 4 attn_v4 first
+  const bool use_v3 = fast != 0;
   constexpr int QT = NW * 32 * QB;
   WmAttnArgs a = a_in;
   a.only_if = nullptr;
@@ -722,7 +723,8 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
     // (the short per-frame sequences — 22 key tiles — lose 10 % with the general kernel and are left alone there; the pipelined
     //  kernel splits them too: 768 units on 512 slots = 512 whole + 256 x 2 halves = two even rounds)
     if (!a.force_partial && a_in.kv_splits == 0 && wm_tuning[WM_TUNE_ATTN_SPLITS] <= 0 && lim >= 2 && ntiles >= (use_v3 ? 16 : 64) && blocks > slots && tail > 0 && wm_tuning[WM_TUNE_ATTN_TAIL] != 0) {
-      auto round_cost = [&](long n) { const long rem = n % slots; return (double)(n / slots) + (rem == 0 ? 0.0 : rem * 2 <= slots ? 0.73 : 1.0); };
+      // (one block per CU — attn_v4 — has no partner to lose: a half-filled round costs a whole one)
+      auto round_cost = [&](long n) { const long rem = n % slots; return (double)(n / slots) + (rem == 0 ? 0.0 : (rem * 2 <= slots && fast != 4) ? 0.73 : 1.0); };
       double best_cost = round_cost(tail);
       int bs = 1;
       for (int S = 2; S <= lim; ++S) {
@@ -737,9 +739,9 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, bool use_v3 = false) {
   const int units = tiles_per_seq * nseq * a.H;
   const int nfull = a.kv_splits > 1 ? a.full_units : units;
   dim3 grid(nfull + (units - nfull) * a.kv_splits), block(NW * 64);
-  if (use_v3) {  // same unit / split numbering (QT = 256): the fast no-max kernel, then the general kernel on the blocks it flagged
+  if (use_v3) {  // same unit / split numbering (QT = 256 / 512): the fast kernel, then the general kernel on the blocks it flagged
     static const int v3_minw = [] { const char* e = getenv("WM_ATTN_V3_MINW"); return e ? atoi(e) : 2; }();
-    hipError_t e = wm_launch_attention_v3(a, (int)grid.x, a.unit_flags, v3_minw, s);
+    hipError_t e = fast == 4 ? wm_launch_attention_v4(a, (int)grid.x, a.unit_flags, s) : wm_launch_attention_v3(a, (int)grid.x, a.unit_flags, v3_minw, s);
     if (e != hipSuccess) return e;
     a.only_if = a.unit_flags;
   }
@@ -764,11 +766,38 @@ hipError_t wm_launch_attention_combine(const WmAttnArgs& a_in, int slots, hipStr
   return hipGetLastError();
 }
 
+// Which kernel a launch takes (the attn_qb numbering of the tuning interface), or -1 for an invalid request:
+//   7  attn_v3 (attention_v3.hip): bf16, software-pipelined, no running max, two waves per SIMD, 256-row units
+//   8  attn_v4 (attention_v4.hip): one wave per SIMD, 128 query rows per wave, 512-row units; bf16 (no max) and f16 (fixed
+//      integer max in the QK chain's initial accumulator) — the default for f16, whose only other kernel is the general one
+//      (tools/bench_attn_v4.py, 32 views: 1151-1156 vs 1026-1031 TF/s; bf16: 1243 vs attn_v3's 1235-1238, a tie)
+//   3  general kernel (integer running max), 64 rows per wave at 2 waves / SIMD: everything else on long sequences, and every
+//      piecewise (force_partial) launch that is not 7 / 8
+//   4  general kernel, 32 rows per wave at 3 waves / SIMD: the short per-frame / DINO sequences
+// 7 and 8 need a flag workspace and key segments of whole 64-key tiles (>= 512 keys); other values: A/B variants (forced only).
+int wm_attention_variant(const WmAttnArgs& a) {
+  static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
+  const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
+  const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
+  const bool fast_ok = a.unit_flags != nullptr && seg_rows >= 512 && seg_rows % 64 == 0;
+  const bool v3ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows >= 512 && (seg_rows % 64 == 0 || a.kv_chunks == 1);
+  int qb = forced ? forced : (seg_rows % 64 == 0 ? (a.dtype == WM_T_BF16 ? 7 : 8) : 0);
+  if ((qb == 7 && !v3ok) || (qb == 8 && !fast_ok) || qb == 0) qb = (a.kv_chunks == 1 && a.seq_len <= 2048) ? 4 : 3;
+  // piecewise launches (the overlapped K/V gather of a sharded forward) write partials for every unit: kernels 3, 7 and 8 do;
+  // a short or ragged local chunk (one view per rank: 1376 keys) would otherwise pick 4
+  if (a.force_partial && qb != 7 && qb != 8 && qb != 3) qb = forced ? -1 : 3;
+  return qb;
+}
+// query rows per unit and resident blocks per CU of the kernel a launch takes (for callers that size key slices)
+void wm_attention_geometry(const WmAttnArgs& a, int* unit_rows, int* blocks_per_cu) {
+  const int qb = wm_attention_variant(a);
+  *unit_rows = qb == 8 ? 512 : qb == 4 || qb == 11 ? 128 : 256;
+  *blocks_per_cu = qb == 8 ? 1 : qb == 4 || qb == 11 ? 3 : 2;
+}
+
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (a.q_rows <= 0) return hipSuccess;
   if (a.seq_len <= 0 || a.q_rows % a.seq_len != 0 || a.kv_chunks < 1) return hipErrorInvalidValue;
-  static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
-  const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
   // 64 rows per wave at 2 waves/SIMD with the lazy max for the long cross-view sequences; the short per-frame / DINO sequences
   // (22 key tiles) run 3-10 % faster as 128-row blocks of 32 rows per wave at 3 waves/SIMD (finer q-tiles: 10.75 -> 11 instead
   // of 5.4 -> 6 per frame, and more waves to overlap; tools/bench_attn_qb.py: 84 vs 87 us at 8 views, 287 vs 313 us at 32)
@@ -778,12 +807,14 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   // tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views.  The per-frame / DINO sequences
   // (1376 / 1374 keys = 21.5 tiles) have a ragged last tile: the v3 instantiation that masks it needs one wave per SIMD and
   // loses to (4) there (122 vs 86 us at 8 views), so it runs only when forced (WM_ATTN_QB=7 / tuning: the parity tests do).
+  const int qb = wm_attention_variant(a);
+  if (qb < 0) return hipErrorInvalidValue;
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
-  const bool v3ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows >= 512 && (seg_rows % 64 == 0 || a.kv_chunks == 1);
-  int qb = forced ? forced : (seg_rows % 64 == 0 ? 7 : 0);
-  if ((qb == 7 && !v3ok) || qb == 0) qb = (a.kv_chunks == 1 && a.seq_len <= 2048) ? 4 : 3;
-  if (a.force_partial && qb != 7 && qb != 3) return hipErrorInvalidValue;  // piecewise launches share the 256-row unit numbering
-  if (qb == 7) return launch<WM_T_BF16, 4, 2, 2>(a, s, true);
+  if (qb == 7) return launch<WM_T_BF16, 4, 2, 2>(a, s, 3);
+  if (qb == 8) {  // attn_v4: 512-row units, one block per CU; the flagged units re-run on 8 waves x 64 rows of the general kernel
+    if (!a.unit_flags || seg_rows % 64 != 0) return hipErrorInvalidValue;
+    return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 8, 2, 2>(a, s, 4) : launch<WM_T_F16, 8, 2, 2>(a, s, 4);
+  }
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);
   if (qb == 10) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 2, 2, 0>(a, s) : launch<WM_T_F16, 4, 2, 2, 0>(a, s);  // eager max (A/B)
   if (qb == 11) return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 4, 1, 3, 0>(a, s) : launch<WM_T_F16, 4, 1, 3, 0>(a, s);

@@ -61,6 +61,9 @@ __device__ __forceinline__ void dma16(const void* sbase, uint32_t voff, uint32_t
 }
 
 // sched_group_barrier masks (LLVM SchedGroupMask)
+#ifdef WM_ATTN_STAMPS
+__device__ unsigned long long wm_attn3_stamp_buf[4 * 8192];   // diagnostic build only (see attention_v4.hip)
+#endif
 #define SG_VALU 0x002
 #define SG_MFMA 0x008
 #define SG_DSRD 0x100
@@ -301,6 +304,11 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   if (nt > 1) dma_v();   // V(1)
   __builtin_amdgcn_sched_barrier(0);
 
+#ifdef WM_ATTN_STAMPS
+  unsigned long long stamp_c0 = 0, stamp_r0 = 0;
+  if (tid == 0) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   // tile 0: step 0 = QK(0); step 1 = QK(1) + SM(0)
   uint32_t ka[4], kb[4];
   lds_k(ka, 0);
@@ -377,6 +385,15 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     pv(1);
   }
 
+#ifdef WM_ATTN_STAMPS
+  if (tid == 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x < 8192) {
+      unsigned long long* o = wm_attn3_stamp_buf + (size_t)blockIdx.x * 4;
+      o[0] = c1 - stamp_c0; o[1] = r1 - stamp_r0; o[2] = (unsigned long long)nt; o[3] = stamp_r0;
+    }
+  }
+#endif
   // ---- row sums; the no-max form is valid iff every row's sum is a comfortably normal number
   float l[QB];
   bool bad = false;
@@ -437,3 +454,10 @@ hipError_t wm_launch_attention_v3(const WmAttnArgs& a, int grid, int* flags, int
   else hipLaunchKernelGGL((attn_v3_kernel<1, false>), dim3(grid), dim3(256), 0, s, a, flags);
   return hipGetLastError();
 }
+
+#ifdef WM_ATTN_STAMPS
+extern "C" int wm_debug_attn3_stamps(unsigned long long* host_out, int nblocks) {
+  if (nblocks > 8192) nblocks = 8192;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wm_attn3_stamp_buf), (size_t)nblocks * 4 * sizeof(unsigned long long));
+}
+#endif

@@ -72,7 +72,11 @@ struct WmAttnArgs {
 // finishes every unit (q_rows x H) over `slots` partial slots written by force_partial launches; O 16-bit [q_rows][H*64]
 hipError_t wm_launch_attention_combine(const WmAttnArgs& a, int slots, hipStream_t s);
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s);
+int wm_attention_variant(const WmAttnArgs& a);                                            // which kernel the launch takes (attention.hip)
+void wm_attention_geometry(const WmAttnArgs& a, int* unit_rows, int* blocks_per_cu);   // its unit size and residency
 hipError_t wm_launch_attention_v3(const WmAttnArgs& a, int grid, int* flags, int minw, hipStream_t s);
+// one wave per SIMD, 128 query rows per wave, 512-row units (attention_v4.hip): bf16 (no max) and f16 (lazy integer max)
+hipError_t wm_launch_attention_v4(const WmAttnArgs& a, int grid, int* flags, hipStream_t s);
 // upper bound of the launch grid (units x splits) for sizing unit_flags
 inline size_t wm_attention_max_blocks(int q_rows, int seq_len, int H) {
   const size_t nseq = (size_t)(q_rows / (seq_len > 0 ? seq_len : 1));

@@ -834,9 +834,17 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
       char* KVG = B<char>(h, "KVG");
       const int rank = h->comm.rank, world = d.world;
       LCHK(c, hipEventRecord(h->cfork, c.s));
-      // slice counts: minimise rounds x tiles per block over the 2-blocks-per-CU slots, per launch (uniform slices only)
+      // slice counts: minimise rounds x tiles per block over the resident slots, per launch (uniform slices only)
       static const int ncu = [] { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
-      const long slots = 2L * ncu, units = (long)((M + 255) / 256) * heads;
+      // (unit size and residency of the kernel these launches take: 256-row units at two blocks per CU, or attn_v4's 512-row
+      //  units at one — f16)
+      int unit_rows = 256, per_cu = 2;
+      {
+        WmAttnArgs g = a;
+        g.force_partial = 1; g.seq_len = M; g.kv_chunks = 1;
+        wm_attention_geometry(g, &unit_rows, &per_cu);
+      }
+      const long slots = (long)per_cu * ncu, units = (long)((M + unit_rows - 1) / unit_rows) * heads;
       auto pick = [&](int ntiles, int smax) {
         int best = 1; long best_cost = -1;
         for (int S = 1; S <= smax && S * 8 <= ntiles; ++S) {

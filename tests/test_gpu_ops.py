@@ -329,7 +329,7 @@ def test_attention_result_independent_of_key_partitioning(dev, H, L, chunks, spl
         assert diff < 0.02 and e < 3e-4
 
 
-def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev):
+def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev, dt=BF16):
     o = torch.zeros(R, H * 64, device=dev, dtype=torch.int16)
     po = torch.zeros((8, R, H * 64), device=dev)
     pml = torch.zeros((8, H, R, 2), device=dev)
@@ -337,11 +337,11 @@ def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert L_.wm_set_tuning(b"attn_qb", qb) == 0
     try:
-        assert L_.wm_op_attention_ex(BF16, _p(q), _p(k), _p(v), _p(o), H, R, Ls, chunks, Lc, splits, _p(po), _p(pml), _p(flags), s) == 0
+        assert L_.wm_op_attention_ex(dt, _p(q), _p(k), _p(v), _p(o), H, R, Ls, chunks, Lc, splits, _p(po), _p(pml), _p(flags), s) == 0
         torch.cuda.synchronize()
     finally:
         L_.wm_set_tuning(b"attn_qb", -1)
-    return _from16(o, BF16).reshape(R, H, 64), flags
+    return _from16(o, dt).reshape(R, H, 64), flags
 
 
 @pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0),
@@ -407,6 +407,100 @@ def test_attention_v3_out_of_range_rows_are_recomputed(dev, kind):
     assert _rel(a7, ref) < 1e-2
     used = flags[: H * (L // 256)]
     assert int(used.sum()) >= 1 and int(used.sum()) <= 2 * len(expect) + 6, used.tolist()   # only the affected units (+ their head's neighbours at most)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0),
+                                                     (2, 1, 576, 1, 1), (5, 3, 1024, 1, 0)])
+def test_attention_v4_one_wave_per_simd(dev, H, nseq, L, chunks, splits, dt):
+    """attention_v4.hip (attn_qb = 8): one wave per SIMD, 128 query rows per wave, every MFMA gap a hand-placed asm statement; bf16
+    without a running max, f16 with the row max fixed from the first key tile (+ headroom) in the QK chain's initial accumulator.
+    Same operands -> the general kernel's result up to final-rounding flips (integer max: the mantissa of P does not depend on it),
+    fp32 softmax within the 16-bit P / O rounding.  Whole units, uniform splits, chunked keys, the tail split (16 heads x 22 q-tiles
+    = 352 units on 256 slots), several sequences, a 576-key sequence (9 tiles: the shortest pipelines), a last q-tile with 64 of
+    512 rows (576 = 512 + 64)."""
+    L_ = _lib()
+    g = torch.Generator().manual_seed(H * 13 + L + chunks)
+    R = nseq * L
+    Lc = L // chunks if chunks > 1 else 0
+    q = _t16(torch.randn(H, R, 64, generator=g) * 0.125 * 1.5 * LOG2E, dt).to(dev)
+    if chunks > 1:
+        k = _t16(torch.randn(chunks, H, Lc, 64, generator=g) * 1.5, dt).to(dev)
+        v = _t16(torch.randn(chunks, H, Lc, 64, generator=g), dt).to(dev)
+    else:
+        k = _t16(torch.randn(H, R, 64, generator=g) * 1.5, dt).to(dev)
+        v = _t16(torch.randn(H, R, 64, generator=g), dt).to(dev)
+    a3, _ = _run_attn_ex(L_, q, k, v, H, R, L, chunks, Lc, splits, 3, dev, dt)
+    a8, flags = _run_attn_ex(L_, q, k, v, H, R, L, chunks, Lc, splits, 8, dev, dt)
+    used = flags[flags >= 0]
+    assert used.numel() > 0, "the v4 kernel did not run (launcher fell back)"
+    assert int(used.sum()) == 0, "no unit may be flagged on bounded scores"
+    diff, e = float((a8 != a3).float().mean()), _rel(a8, a3)
+    print(f"v4 vs general dt{dt} H{H} nseq{nseq} L{L} chunks{chunks} splits{splits}: {100 * diff:.3f} % of the outputs differ, rel-L2 {e:.2e}; blocks {used.numel()}")
+    assert torch.isfinite(a8).all() and diff < (0.02 if dt == BF16 else 0.06) and e < (3e-4 if dt == BF16 else 8e-5)
+    kk = (torch.cat(list(k), 1) if chunks > 1 else k).float()
+    vv = (torch.cat(list(v), 1) if chunks > 1 else v).float()
+    for i in range(nseq):
+        sl = slice(i * L, (i + 1) * L)
+        ks = kk if chunks > 1 else kk[:, sl]
+        vs = vv if chunks > 1 else vv[:, sl]
+        ref = _attn_ref(q[:, sl].float(), ks, vs).transpose(0, 1)
+        assert _rel(a8[sl], ref) < (8e-3 if dt == BF16 else 1e-3)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_attention_v4_matches_emulated_rounding(dev, dt):
+    """Kernel error proper for attn_v4: against the rounding-emulated softmax (integer row max, P rounded to 16 bits, fp32 row
+    sums) on the same operands the 16-bit output is identical except for final-rounding flips.  f16: the emulation subtracts the
+    TRUE integer row max, the kernel a max fixed after 64 keys + 4: a different power of two, i.e. the same mantissas — only
+    P below 2^-14 of the respective reference point round differently (subnormal), far below the output's ulp."""
+    L_ = _lib()
+    H, L = 4, 2752
+    g = torch.Generator().manual_seed(H + L)
+    q = _t16(torch.randn(H, L, 64, generator=g) * 0.125 * 1.5 * LOG2E, dt).to(dev)
+    k = _t16(torch.randn(H, L, 64, generator=g) * 1.5, dt).to(dev)
+    v = _t16(torch.randn(H, L, 64, generator=g), dt).to(dev)
+    got, flags = _run_attn_ex(L_, q, k, v, H, L, L, 1, 0, 1, 8, dev, dt)
+    assert int(flags[flags >= 0].sum()) == 0
+    emu = _attn_emulated(q.float(), k.float(), v.float(), dt).transpose(0, 1)
+    diff, e = float((got != emu).float().mean()), _rel(got, emu)
+    print(f"v4 vs emulated rounding dt{dt}: {100 * diff:.3f} % of the outputs differ (by one 16-bit ulp), rel-L2 {e:.2e}")
+    assert diff < (0.02 if dt == BF16 else 0.06) and e < (3e-4 if dt == BF16 else 8e-5)
+
+
+@pytest.mark.parametrize("dt,kind", [(BF16, "spike_overflow"), (BF16, "all_far_below_zero"), (F16, "late_spike"), (F16, "all_far_below_zero")])
+def test_attention_v4_out_of_range_rows_are_recomputed(dev, dt, kind):
+    """The fast forms are only valid inside a range that is checked, not assumed: bf16 — every row sum in [2^-80, 2^100]; f16 — no
+    P beyond f16 (a score more than 2^20 above what the row's first 64 keys showed: O turns non-finite) and a row sum that is a
+    normal number.  A unit with such a row raises its flag and comes out right from the general kernel's recompute pass; all
+    other units are left to the fast kernel."""
+    L_ = _lib()
+    H, L = 2, 2048
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(H, L, 64, generator=g) * 0.125 * LOG2E
+    k = torch.randn(H, L, 64, generator=g)
+    v = torch.randn(H, L, 64, generator=g)
+    if kind == "spike_overflow":
+        k[0, 1500] = q[0, 700] * 8 * 60.0        # head 0, query row 700 (unit 1): one score ~ +300 in log2 units
+        expect = {(0, 1)}
+    elif kind == "late_spike":
+        k[0, 1500] = q[0, 700] * 8 * 9.0         # ~ +45 log2 units at key 1500: far above the window set after the first 64 keys
+        expect = {(0, 1)}
+    else:
+        base = torch.randn(64, generator=g)
+        q[1, 512:1024] = (base + 0.05 * torch.randn(512, 64, generator=g)) * 3.0   # head 1, unit 1: every score ~ -600
+        k[1] = -(base + 0.05 * torch.randn(L, 64, generator=g)) * 3.0
+        expect = {(1, 1)}
+    q, k, v = [_t16(x, dt).to(dev) for x in (q, k, v)]
+    a8, flags = _run_attn_ex(L_, q, k, v, H, L, L, 1, 0, 1, 8, dev, dt)
+    ref = _attn_ref(q.float(), k.float(), v.float()).transpose(0, 1)
+    assert torch.isfinite(a8).all()
+    assert _rel(a8, ref) < (1e-2 if dt == BF16 else 2e-3)
+    used = flags[: H * (L // 512)]
+    nflag = int((used != 0).sum())
+    print(f"v4 {kind} dt{dt}: flags {used.tolist()}")
+    if not (dt == F16 and kind == "all_far_below_zero"):   # (f16 subtracts a max: uniformly low scores are in range there)
+        assert 1 <= nflag <= 2 * len(expect) + 2, used.tolist()
 
 
 @pytest.mark.parametrize("D", [128, 256, 1024, 2048])

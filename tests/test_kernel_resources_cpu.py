@@ -46,6 +46,49 @@ def test_attention_v3_fits_two_waves_per_simd_without_scratch(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_attention_v4_register_file_split_and_clean_loop(tmp_path):
+    """attn_v4_kernel (attention_v4.hip) owns a SIMD: O and Q in 192 AGPRs, everything the VALU touches in arch VGPRs, nothing in
+    scratch.  Scratch would not only be slow: spill loads / stores count in vmcnt and would break the kernel's hand-counted
+    `s_waitcnt vmcnt(4)` for its LDS-DMA pieces (seen: a spilling f16 variant read K / V tiles before they had landed and flagged
+    every unit).  The loop must hold no v_accvgpr_* copy (a first form through MFMA builtins had 44-80 per iteration) and exactly
+    the instruction mix the schedule is built on: per 64 MFMAs 128 v_exp, 128 v_add, 64 packs, 24 LDS fragment reads."""
+    flags = None
+    for line in open(os.path.join(CSRC, "Makefile")):
+        if line.startswith("CXXFLAGS"):
+            flags = [f.replace("$(ARCH)", "gfx950") for f in line.split("=", 1)[1].split() if not f.startswith("$(")]
+    asm = tmp_path / "v4.s"
+    r = subprocess.run(["hipcc", *flags, "-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, "attention_v4.hip"), "-o", str(asm),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    n = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "attn_v4_kernel" not in name:
+            continue
+        n += 1
+        get = lambda key: int(re.search(key + r": (\d+)", b).group(1))
+        assert get(r"ScratchSize \[bytes/lane\]") == 0 and get(r"VGPRs Spill") == 0 and get(r"SGPRs Spill") == 0, b[:400]
+        assert get(r"AGPRs") == 192 and get(r"VGPRs") <= 256, b[:400]
+    assert n == 2
+    text = open(asm).read()
+    kernels = re.findall(r"^(_ZN\S*attn_v4_kernel\S*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 2
+    for name, body in kernels:
+        lines = body.split("\n")
+        head = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
+        first = [i for i, l in enumerate(lines) if "in Loop: Header" in l]
+        assert len(head) == 1 and first, name
+        loop = lines[first[0]:head[0]]       # the tile loop's body block precedes its header block in the listing
+        count = lambda pat: sum(1 for l in loop if re.search(pat, l))
+        assert count(r"v_mfma_f32_32x32x16") == 64, (name, count(r"v_mfma_f32_32x32x16"))
+        assert count(r"v_accvgpr") == 0 and count(r"scratch_") == 0, name
+        assert count(r"v_exp_f32") == 128 and count(r"v_add_f32") == 128 and count(r"v_cvt_pk_") == 64, name
+        assert count(r"ds_read") == 24, (name, count(r"ds_read"))
+        assert count(r"s_nop") <= 20, (name, count(r"s_nop"))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 def test_no_packed_fp32_instruction_outside_the_gelu_gemm(tmp_path):
     """With two or more HIP queues active a packed-fp32 VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) can lose a
     half result (profiles/r02_multiqueue_hazard.md).  The forward uses extra queues in two places — the DPT heads + camera head

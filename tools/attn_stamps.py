@@ -1,0 +1,61 @@
+"""In-kernel clock and cycles per MFMA of the cross-view attention kernels (guides/MI355X_MICROARCH.md, DVFS give-back item 6).
+
+Needs the diagnostic build:  make -C hunyuanworld-mirror_amd/csrc stamps   and   WM_HIP_LIB=hunyuanworld-mirror_amd/libwm_hip_stamps.so
+In that build wave 0 of every block stamps s_memtime / s_memrealtime before and after its tile loop into a buffer of its own
+(no output depends on it).  Here: >= 2 s of back-to-back launches on random gaussian data, then one more launch whose stamps are
+read: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, cycles per MFMA = d(s_memtime) / (MFMAs a wave issues in the
+loop), medians over the whole (unsplit) blocks.  Run times of this build are not quoted.
+usage: WM_HIP_LIB=... python tools/attn_stamps.py [bf16|f16] [views...]"""
+import ctypes as C, json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from hunyuanworld_mirror_amd import _lib
+L = _lib.lib(); dev = torch.device('cuda:0')
+assert hasattr(L, "wm_debug_attn_stamps"), "not the stamps build: set WM_HIP_LIB to libwm_hip_stamps.so"
+p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+args = sys.argv[1:]
+dt_name = args.pop(0) if args and args[0] in ("bf16", "f16") else "bf16"
+dt = 0 if dt_name == "bf16" else 1
+tdt = torch.bfloat16 if dt == 0 else torch.float16
+views = [int(x) for x in args] or [8, 32]
+H = 16
+for nv in views:
+    M = nv * 1376
+    g = torch.Generator(device="cpu").manual_seed(1)
+    q = (torch.randn(H, M, 64, generator=g) * 0.125 * 1.4427 * 1.5).to(tdt).to(dev)
+    k = (torch.randn(1, H, M, 64, generator=g) * 1.5).to(tdt).to(dev)
+    v = torch.randn(1, H, M, 64, generator=g).to(tdt).to(dev)
+    o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
+    po = torch.empty(8, M, H * 64, device=dev); pml = torch.empty(8, H, M, 2, device=dev)
+    flags = torch.zeros((int(L.wm_op_attention_flag_count(M, M, H)),), device=dev, dtype=torch.int32)
+    fl = 4.0 * M * M * 64 * H
+    def run():
+        assert L.wm_op_attention_ex(dt, p(q), p(k), p(v), p(o), H, M, M, 1, 0, 0, p(po), p(pml), p(flags), s) == 0
+    for qb, fn, rows, mf_tile in ((7, "wm_debug_attn3_stamps", 256, 32), (8, "wm_debug_attn_stamps", 512, 64)):
+        if qb == 7 and dt != 0:
+            continue
+        assert L.wm_set_tuning(b"attn_qb", qb) == 0
+        t0 = time.time(); n = 0
+        while time.time() - t0 < 2.5:
+            for _ in range(8): run()
+            torch.cuda.synchronize(); n += 8
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        units = ((M + rows - 1) // rows) * H
+        nb = min(units, 8192)
+        buf = (C.c_ulonglong * (nb * 4))()
+        assert getattr(L, fn)(buf, nb) == 0
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 4).astype(np.float64)
+        whole = a[a[:, 2] == (M // 64)]          # blocks that walked every key tile
+        cyc, rt, nt = whole[:, 0], whole[:, 1], whole[:, 2]
+        clk = cyc / rt * 100.0                   # MHz
+        cpm = cyc / (nt * mf_tile)
+        print(json.dumps({"views": nv, "dtype": dt_name, "attn_qb": qb, "whole_blocks": int(len(whole)), "launch_us_stamp_build": round(ms * 1e3, 1),
+                          "tflops_stamp_build": round(fl / ms / 1e9), "in_kernel_clock_mhz_median": round(float(np.median(clk)), 1),
+                          "in_kernel_clock_mhz_p10_p90": [round(float(np.percentile(clk, 10)), 1), round(float(np.percentile(clk, 90)), 1)],
+                          "cycles_per_mfma_median": round(float(np.median(cpm)), 2), "cycles_per_mfma_p10_p90": [round(float(np.percentile(cpm, 10)), 2), round(float(np.percentile(cpm, 90)), 2)],
+                          "loop_us_median": round(float(np.median(rt)) / 100.0, 1)}), flush=True)
+    L.wm_set_tuning(b"attn_qb", -1)
