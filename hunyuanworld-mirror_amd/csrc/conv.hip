@@ -228,7 +228,7 @@ hipError_t wm_launch_conv3x3(const WmConvArgs& a, hipStream_t s);
 
 hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s) {
   if (a.N <= 0) return hipSuccess;
-  static const bool no_halo = getenv("WM_CONV_GENERIC") != nullptr;
+  const bool no_halo = wm_conv_force_generic();   // (wm_conv3x3_out16_ok knows the switch too: no out16 grant that this launch cannot honour)
   if (a.up_hs > 0) {  // fused input upsample exists in the halo kernel only; callers test wm_conv3x3_applicable first
     if (!wm_conv3x3_applicable(a) || a.up_ws <= 0 || (a.up_addx && (a.Cin & 15))) return hipErrorInvalidValue;
     return wm_launch_conv3x3(a, s);

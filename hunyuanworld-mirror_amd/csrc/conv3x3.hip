@@ -719,8 +719,12 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+bool wm_conv_force_generic() {  // WM_CONV_GENERIC (A/B switch): every conv through the generic kernel of conv.hip
+  static const bool g = getenv("WM_CONV_GENERIC") != nullptr;
+  return g;
+}
 bool wm_conv3x3_out16_ok(const WmConvArgs& a) {  // exactly the launches launch_T sends to conv3x3_rs_kernel with a plain input
-  return wm_conv3x3_applicable(a) && a.up_hs == 0 && (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0 && pick_bn(a) >= 128;
+  return !wm_conv_force_generic() && wm_conv3x3_applicable(a) && a.up_hs == 0 && (a.Cin / 64) % 2 == 0 && wm_tuning[WM_TUNE_CONV_RS] != 0 && pick_bn(a) >= 128;
 }
 
 bool wm_conv3x3_applicable(const WmConvArgs& a) {

@@ -221,11 +221,15 @@ __global__ __launch_bounds__(256) void gs_splat_kernel(const float* __restrict__
     float tc[3];
     for (int a = 0; a < 3; ++a) tc[a] = -(R[0 * 3 + a] * v[0] + R[1 * 3 + a] * v[1] + R[2 * 3 + a] * v[2]);
     for (int a = 0; a < 3; ++a) means[i * 3 + a] = R[0 * 3 + a] * xc + R[1 * 3 + a] * yc + R[2 * 3 + a] * zc + tc[a];
-    if (dbg) {  // WM_DBG_SPLAT: dump the camera vector this thread READ in place of the other attributes (tools/dbg_c5.py)
+#ifdef WM_DBG_SPLAT_BUILD   // diagnostic builds only (-DWM_DBG_SPLAT_BUILD, then WM_DBG_SPLAT=1): dump the camera vector this thread READ in
+    if (dbg) {              // place of the other attributes (tools/dbg_c5.py) — a product build cannot be made to corrupt its splats
       opac[i] = v[0]; wts[i] = v[1]; scales[i * 3 + 0] = v[2]; scales[i * 3 + 1] = v[7]; scales[i * 3 + 2] = v[8];
       quats[i * 4 + 0] = v[3]; quats[i * 4 + 1] = v[4]; quats[i * 4 + 2] = v[5]; quats[i * 4 + 3] = v[6];
       sh[i * 3 + 0] = tc[0]; sh[i * 3 + 1] = tc[1]; sh[i * 3 + 2] = tc[2];
     }
+#else
+    (void)dbg;
+#endif
   }
 }
 
@@ -508,7 +512,11 @@ hipError_t wm_launch_im2col7(const float* img, void* out, int N, int H, int W, i
 hipError_t wm_launch_gs_splat(const float* gp, const float* img, const float* depth, const float* cam, float* means, float* quats,
                               float* scales, float* opac, float* sh, float* wts, int N, int H, int W, hipStream_t s) {
   if (!N) return hipSuccess;
+#ifdef WM_DBG_SPLAT_BUILD
   static const int dbg = getenv("WM_DBG_SPLAT") ? 1 : 0;
+#else
+  const int dbg = 0;
+#endif
   hipLaunchKernelGGL(gs_splat_kernel, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, s, gp, img, depth, cam, means, quats, scales,
                      opac, sh, wts, N, H, W, dbg);
   return hipGetLastError();

@@ -32,9 +32,11 @@ __device__ __forceinline__ u16 f2bf(float x) {  // round-to-nearest-even, NaN pr
 __device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, ((uint32_t)v) << 16); }
 // fp32 -> f16 SATURATES at +-65504 (one v_med3_f32): the reference's DPT heads are fp32 (worldmirror.py:146) and an unbounded
 // ReLU / residual chain of a real checkpoint may exceed f16's range; an inf operand would turn a whole MFMA row into NaN.
-// A NaN input comes out as -65504 (v_med3 orders NaN low), i.e. it is not propagated.
+// A NaN stays a NaN (v_med3 alone would order it low and return -65504: an upstream fault would come out as plausible finite
+// values where the reference's fp32 heads return NaN): one v_cmp + v_cndmask more.
 __device__ __forceinline__ u16 f2h(float x) {
-  x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+  const float c = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+  x = x != x ? x : c;
   _Float16 h = (_Float16)x;
   return __builtin_bit_cast(u16, h);
 }
@@ -97,9 +99,16 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
   const f32x2_t hx = x * k(0.5f), ah = ax * k(0.5f);
   return __builtin_elementwise_fma(-ah, p * t * e, hx + ah);
 }
+// WM_UNPACKED_GELU (make EXTRA=-DWM_UNPACKED_GELU): the scalar form, no packed-fp32 instruction anywhere in the library — for a
+// deployment that drives several handles on one device from different threads / streams (wm_share_weights) and wants the
+// multi-queue guarantee of profiles/r02_multiqueue_hazard.md for the fc1 GEMM too (~ +0.4 ms per 8-view forward).
 __device__ __forceinline__ float4 gelu_erf4(float4 x) {
+#ifdef WM_UNPACKED_GELU
+  return make_float4(gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w));
+#else
   const f32x2_t a = gelu_erf2(f32x2_t{x.x, x.y}), b = gelu_erf2(f32x2_t{x.z, x.w});
   return make_float4(a.x, a.y, b.x, b.y);
+#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

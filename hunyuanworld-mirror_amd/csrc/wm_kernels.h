@@ -152,6 +152,7 @@ struct WmConvArgs {
   int dbg;             // timing experiments only (builds with -DWM_CONV_TIMING_EXPERIMENT; results are wrong): 1 no halo refill, 2 no epilogue, 4 no weight refill
 };
 bool wm_conv3x3_applicable(const WmConvArgs& a);
+bool wm_conv_force_generic();                     // WM_CONV_GENERIC set
 bool wm_conv3x3_out16_ok(const WmConvArgs& a);   // the launch would take a kernel that implements out16
 // 3x3 / s1 / p1 conv with 32 output channels on a 16-bit NHWC input (conv_n32.hip); zero: >= 16 B of device zeros
 struct WmConvN32Args {

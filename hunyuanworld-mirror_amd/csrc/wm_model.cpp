@@ -811,16 +811,29 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     memset(&a, 0, sizeof(a));
     a.Q = Q16; a.O = O16; a.H = heads; a.q_rows = M; a.q_head_stride = M; a.dtype = dt;
     static const bool force_gather = getenv("WM_FORCE_GATHER") != nullptr;  // 1-rank test of the collective path
-    // On by default for a sharded forward (WM_COMM_OVERLAP=0 / tuning comm_overlap = 0: gather on the compute queue).  The second
-    // queue is safe here: between fork and join the compute queue runs only the attention kernels, which contain no packed-fp32
-    // instruction (the hazard described at the DPT heads below needs one; tests/test_kernel_resources_cpu.py disassembles them)
-    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return !e || atoi(e) != 0; }();
+    // Opt-in (WM_COMM_OVERLAP=1 / tuning comm_overlap = 1; default: the gather on the compute queue): the overlapped form is
+    // exercised by 8 in-process ranks on one GPU (tests/test_gpu_fullsize.py), but RCCL has not run it on real links yet
+    // (no multi-GPU node was available to any round): the simpler event-free path is the default until one 8-GPU run of both,
+    // compared bit for bit, is on record.  The second queue is safe here: between fork and join the compute queue runs only
+    // the attention kernels, which contain no packed-fp32 instruction (the hazard described at the DPT heads below needs one;
+    // tests/test_kernel_resources_cpu.py disassembles them)
+    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return e && atoi(e) != 0; }();
     a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
     a.unit_flags = B<int>(h, "ATT_FLAGS");
     const bool sharded = is_global && (d.world > 1 || (force_gather && h->comm.kind != 0));
     const int ntpc = (M + 63) / 64;  // key tiles per rank chunk
     const bool overlap = wm_tuning[WM_TUNE_COMM_OVERLAP] >= 0 ? wm_tuning[WM_TUNE_COMM_OVERLAP] != 0 : overlap_env;
-    if (sharded && overlap && d.world > 1 && ntpc >= 16) {
+    // every launch argument set of the overlapped form is checked BEFORE the fork: a rank that returned between the fork and
+    // the collective would leave its peers waiting in the all-gather
+    bool overlap_ok = sharded && overlap && d.world > 1 && ntpc >= 16;
+    if (overlap_ok) {
+      WmAttnArgs t = a;
+      t.force_partial = 1; t.K = K16; t.V = V16; t.seq_len = M; t.kv_head_stride = M; t.kv_chunks = 1;
+      overlap_ok = wm_attention_variant(t) >= 0;
+      t.kv_chunks = d.world - 1 > 1 ? d.world - 1 : 2; t.kv_rows_per_chunk = M; t.kv_chunk_stride = (long long)(2 * hsz / 2);
+      overlap_ok = overlap_ok && wm_attention_variant(t) >= 0;
+    }
+    if (overlap_ok) {
       // ---- K/V all-gather UNDER the attention over this rank's own keys: the collective runs on the handle's
       // communication queue as soon as the QKV epilogue has written K|V; the compute queue meanwhile attends the local chunk
       // (1 / world of the keys: about the gather's own duration at 8 ranks), then the remote chunks — the gathered buffer's
@@ -1411,6 +1424,11 @@ extern "C" wm_status wm_comm_init_local(wm_handle* h, wm_local_group* g, int ran
   if (!h || !g || rank < 0 || rank >= g->world) return WM_ERR_INVALID;
   h->comm.kind = 2; h->comm.rank = rank; h->comm.world = g->world; h->comm.grp = g;
   return WM_OK;
+}
+
+extern "C" wm_status wm_allgather(wm_handle* h, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
+  if (!h || !send || !recv || bytes_per_rank == 0) return WM_ERR_INVALID;
+  return comm_allgather(h, send, recv, bytes_per_rank, (hipStream_t)stream);
 }
 
 // ====================================================================================== profiling

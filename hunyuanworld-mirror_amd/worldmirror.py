@@ -90,7 +90,7 @@ def extract_priors(views: Dict[str, torch.Tensor]):
     return depths, rays, poses
 
 
-def shard_inputs(views: Dict[str, torch.Tensor], cond_flags, rank: int, world: int, patch_size: int = 14):
+def shard_inputs(views: Dict[str, torch.Tensor], cond_flags, rank: int, world: int, patch_size: int = 14, batch: int = 0):
     """The host-side sharding rules of the view-sharded forward, device-agnostic: validate the input dict as the
     reference does (visual_transformer.py:272-273, patch_embed.py:67-68), normalise the priors over ALL views
     (worldmirror.py:134-141: cross-view statistics come before sharding), then cut the contiguous block of views
@@ -98,8 +98,11 @@ def shard_inputs(views: Dict[str, torch.Tensor], cond_flags, rank: int, world: i
     (img [n,3,H,W], pose [n,7] | None, ray [n,4] | None, depth [n,H,W] | None; fp32, contiguous, on the inputs' device) and
     n, first_view, S, H, W, flags.  Used by WorldMirror.forward and by tests/test_sharding_cpu.py (gloo, world 2)."""
     imgs = views["img"]
-    if imgs.dim() != 5 or imgs.shape[0] != 1:
-        raise ValueError("views['img'] must be [1, S, 3, H, W] (B is always 1 at inference, infer.py:143)")
+    if imgs.dim() != 5:
+        raise ValueError("views['img'] must be [B, S, 3, H, W]")
+    if imgs.shape[0] != 1:   # one batch element at a time (WorldMirror.forward loops; the reference folds B into B*S, visual_transformer.py:271-277)
+        views = {k: (v[batch:batch + 1] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == imgs.shape[0] else v) for k, v in views.items()}
+        imgs = views["img"]
     _, S, ch, H, W = imgs.shape
     if ch != 3:
         raise ValueError(f"Expected 3 input channels, got {ch}")  # visual_transformer.py:272-273
@@ -208,7 +211,11 @@ class WorldMirror:
             raise FileNotFoundError(f"{path}: only local checkpoints are supported (no network)")
         with open(os.path.join(path, "config.json")) as f:
             cfg = json.load(f)
-        m = cls(**{**cfg, **kw})
+        # PyTorchModelHubMixin passes only the keys the constructor's signature names (worldmirror.py:13,16): metadata the hub adds
+        # to config.json ("model_type", library versions, ...) must not reach the constructor
+        import inspect
+        known = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        m = cls(**{**{k: v for k, v in cfg.items() if k in known}, **kw})
         from safetensors import safe_open
         sd = {}
         with safe_open(os.path.join(path, "model.safetensors"), framework="pt", device="cpu") as f:  # "pt": bf16 / f16 checkpoints too
@@ -379,10 +386,42 @@ class WorldMirror:
     def forward(self, views: Dict[str, torch.Tensor], cond_flags: List[int] = [0, 0, 0]):
         if self._handle is None:
             raise RuntimeError("call .to('cuda') first: the forward pass runs in libwm_hip.so on the GPU")
+        B = int(views["img"].shape[0]) if views["img"].dim() == 5 else 1
+        if B == 1:
+            return self._forward_one(views, cond_flags, 0)
+        # B > 1 (visual_transformer.py:271-277 folds the batch into B*S; frame attention is per view and global attention per
+        # batch element, so the elements are independent): one forward per element, outputs stacked along dim 0
+        outs = [self._forward_one(views, cond_flags, b) for b in range(B)]
+        res: Dict[str, torch.Tensor] = {}
+        for k, v0 in outs[0].items():
+            if isinstance(v0, torch.Tensor):
+                res[k] = torch.cat([o[k] for o in outs], 0)
+            elif k == "taps":
+                res[k] = [torch.cat([o[k][i] for o in outs], 0) for i in range(len(v0))]
+            elif k == "splats_raw" or (k == "splats" and isinstance(next(iter(v0.values())), torch.Tensor)):
+                res[k] = {kk: torch.cat([o[k][kk] for o in outs], 0) for kk in v0}
+            else:   # pruned splats: lists over the batch (rasterization.py:301-387)
+                res[k] = {kk: [x for o in outs for x in o[k][kk]] for kk in v0}
+        return res
+
+    def _gather_splats(self, raw: Dict[str, torch.Tensor], world: int):
+        """All ranks' raw splats, rank-major = global view order (contiguous view blocks per rank): [1, world * M, ...]."""
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+        out = {}
+        for k, t in raw.items():
+            t = t.contiguous()
+            g = torch.empty((world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            if L.wm_allgather(self._handle, _lib.ptr(t), _lib.ptr(g), t.numel() * t.element_size(), stream) != 0:
+                raise RuntimeError(f"wm_allgather: {self._err()}")
+            out[k] = g.reshape((1, world * t.shape[1]) + tuple(t.shape[2:]))
+        return out
+
+    def _forward_one(self, views: Dict[str, torch.Tensor], cond_flags, batch: int):
         L = _lib.lib()
         dev = self._device
         rank, world = self._comm if self._comm else (0, 1)
-        sh = shard_inputs(views, cond_flags, rank, world, self.cfg.patch_size)
+        sh = shard_inputs(views, cond_flags, rank, world, self.cfg.patch_size, batch)
         n, v0, S, H, W, flags = sh["n"], sh["first_view"], sh["S"], sh["H"], sh["W"], sh["flags"]
         ps = self.cfg.patch_size
         img_l, pose_l, ray_l, depth_l = [None if sh[k] is None else sh[k].to(dev) for k in ("img", "pose", "ray", "depth")]
@@ -438,7 +477,13 @@ class WorldMirror:
                    "scales": raw["scales"].reshape(1, M, 3), "opacities": raw["opacities"].reshape(1, M),
                    "sh": raw["sh"].reshape(1, M, 1, 3), "weights": raw["weights"].reshape(1, M)}
             res["splats_raw"] = raw
-            res["splats"] = prune_gs(raw) if self.enable_prune else raw
+            if self.enable_prune:
+                # prune_gs merges voxels over ALL views (rasterization.py:301-387): the one cross-view step behind the forward.
+                # A sharded forward gathers the ranks' raw splats (global view order) and every rank merges the full set, so
+                # preds["splats"] is the reference's on every rank (not world separately merged sets)
+                res["splats"] = prune_gs(self._gather_splats(raw, world) if world > 1 else raw)
+            else:
+                res["splats"] = raw
         self._keepalive = (img_l, pose_l, ray_l, depth_l)
         return res
 

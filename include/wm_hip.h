@@ -117,6 +117,10 @@ typedef struct wm_local_group wm_local_group;
 wm_local_group* wm_local_group_create(int world);
 void wm_local_group_destroy(wm_local_group* g);
 wm_status wm_comm_init_local(wm_handle* h, wm_local_group* g, int rank);
+/* All-gather over the handle's communicator (RCCL, or the in-process group), stream-ordered: recv = [world][bytes_per_rank].
+ * For the ONE cross-view step behind the forward: the reference's prune_gs merges the splats of ALL views
+ * (src/models/models/rasterization.py:301-387), so a sharded forward gathers the per-rank raw splats before the merge. */
+wm_status wm_allgather(wm_handle* h, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 
 /* ---- timing hooks used by bench.py: HIP events on the launch stream around kernel classes ---- */
 /* kind: 0 = global attention, 1 = frame+dino attention, 2 = GEMM (epilogues other than the three below), 3 = DPT conv,

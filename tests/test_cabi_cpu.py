@@ -103,7 +103,9 @@ def test_from_pretrained_local_dir(tmp_path):
     sd["not.a.parameter"] = torch.zeros(3)
     d = tmp_path / "ckpt"
     d.mkdir()
-    (d / "config.json").write_text(json.dumps(kw))
+    # metadata keys that huggingface_hub adds to config.json: PyTorchModelHubMixin filters config.json to the constructor's
+    # signature (worldmirror.py:13,16), so they must not reach the constructor
+    (d / "config.json").write_text(json.dumps({**kw, "model_type": "worldmirror", "library_name": "pytorch", "_hub_version": "0.x"}))
     save_file(sd, str(d / "model.safetensors"))
     m = WorldMirror.from_pretrained(str(d), arch=cfg)   # arch: the scaled-down test architecture behind the same kwargs
     assert dropped not in m._host_weights and "not.a.parameter" not in m._host_weights

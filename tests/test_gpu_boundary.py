@@ -138,3 +138,22 @@ def test_shared_weights_between_handles():
     ra2 = a(tv, flags)                                      # the owner is intact after a sharer is destroyed
     torch.cuda.synchronize()
     assert torch.equal(ra2["pts3d"], ra["pts3d"])
+
+
+def test_batch_of_two_equals_two_forwards():
+    """The reference takes [B, S, 3, H, W] (visual_transformer.py:271-277 folds B into B*S; frame attention is per view, global
+    attention per batch element, so elements are independent): B = 2 must equal the two single-element forwards, stacked."""
+    from hunyuanworld_mirror_amd import WorldMirror
+    cfg, views, flags, outs, z = load_golden("tiny_3v_70x56_pose_ray")
+    m = WorldMirror(arch=cfg).init_synthetic_weights().to("cuda:0")
+    tv = {k: torch.from_numpy(v).cuda() for k, v in views.items()}
+    g = torch.Generator().manual_seed(1)
+    tv2 = {k: v.clone() for k, v in tv.items()}
+    tv2["img"] = torch.rand(tv["img"].shape, generator=g).cuda()
+    both = {k: torch.cat([tv[k], tv2[k]], 0) for k in tv}
+    a, b = m(tv, flags), m(tv2, flags)
+    ab = m(both, flags)
+    for k in ("pts3d", "depth", "normals", "camera_params", "camera_poses", "pts3d_conf"):
+        assert ab[k].shape[0] == 2 and torch.equal(ab[k][0:1], a[k]) and torch.equal(ab[k][1:2], b[k]), k
+    if "splats" in ab:
+        assert len(ab["splats"]["means"]) == 2 and torch.equal(ab["splats"]["means"][1], b["splats"]["means"][0])

@@ -18,12 +18,12 @@ from conftest import GOLD, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-# Measured on MI355X (see DESIGN.md "Numerics"): with the sensitivity-maximising synthetic weights (LayerScale 0.3,
-# not the reference's 0.01 init) the bf16 recipe sits at ~3e-3 on pts3d; an f16 backbone reaches the north-star 1e-3.
-TOL_BF16 = {"pts3d": 5e-3, "depth": 2e-3, "normals": 4e-3, "pts3d_conf": 1e-3, "depth_conf": 1e-3, "normals_conf": 1e-3,
-            "camera_params": 5e-3, "camera_poses": 1e-2, "camera_intrs": 5e-3}
-TOL_F16 = {"pts3d": 1.5e-3, "depth": 1e-3, "normals": 2e-3, "camera_params": 1e-3}  # measured 1.0e-3 / 1.4e-4 / 1.1e-3 / 2.6e-4
-TOL = TOL_BF16
+# Accuracy bounds live in tests/test_gpu_emulated.py, where they are DERIVED per fixture from the rounding-emulated oracle
+# (GPU vs emulated <= 1.25 F + 5e-5, GPU vs reference <= 1.15 R + 1e-4; refinit preset: the north-star 1e-3 outright) — the
+# hand-tuned per-output tolerances of round 1 are gone.  This file checks the plumbing of the same fixtures: shapes, finiteness,
+# taps, full-resolution checksums, and a gross-error gate that no recipe noise can reach.
+GROSS = 2e-2
+DENSE = ("pts3d", "depth", "normals", "pts3d_conf", "depth_conf", "normals_conf", "camera_params", "camera_poses", "camera_intrs")
 
 
 def _model(cfg, **kw):
@@ -67,19 +67,20 @@ def test_tiny_golden(name):
     print(name, {k: f"{e:.2e}" for k, e in errs.items()})
     for i in range(4):
         assert errs[f"tap{i}"] < 2e-2
-    for k, tol in TOL.items():
-        assert errs[k] < tol, (k, errs[k])
+    for k in DENSE:
+        assert errs[k] < GROSS, (k, errs[k])
 
 
 def test_tiny_golden_f16_backbone():
-    """dtype='f16' (BASELINE config 5's dtype) must be at least as close as bf16."""
+    """dtype='f16' (BASELINE config 5's dtype: 3 more mantissa bits in every backbone operand) must be closer to the reference than
+    bf16 on the dense outputs — a relation between two measured errors, not a tuned number."""
     cfg, views, flags, outs, z = load_golden("tiny_3v_70x56_pose_ray")
-    m = _model(cfg, dtype="f16")
-    got = _run(m, views, flags)
-    for k in ("pts3d", "depth", "normals", "camera_params"):
-        e = rel_l2(got[k].cpu().numpy(), outs[k])
-        print("\nf16", k, f"{e:.2e}")
-        assert e < TOL_F16[k]
+    got16 = _run(_model(cfg, dtype="f16"), views, flags)
+    gotbf = _run(_cached_model(cfg), views, flags)
+    for k in ("pts3d", "depth", "normals"):
+        e16, ebf = rel_l2(got16[k].cpu().numpy(), outs[k]), rel_l2(gotbf[k].cpu().numpy(), outs[k])
+        print("\nf16 vs bf16 backbone", k, f"{e16:.2e} {ebf:.2e}")
+        assert e16 < 0.75 * ebf, (k, e16, ebf)
 
 
 @pytest.mark.parametrize("name", ["full_2v_224_noprior", "full_2v_224_pose_ray", "full_3v_154x210_allpriors"])
@@ -98,8 +99,8 @@ def test_full_arch_2x224_golden(name):
         assert g.shape == v.shape, k
         errs[k] = rel_l2(g, v)
     print(name, {k: f"{e:.2e}" for k, e in errs.items()})
-    for k, tol in TOL.items():
-        assert errs[k] < tol, (k, errs[k])
+    for k in DENSE:
+        assert errs[k] < GROSS, (k, errs[k])
     # checksum-of-everything property at full resolution (not just the subsampled pixels)
     for k in ("pts3d", "depth", "normals"):
         s = float(got[k].double().sum())
@@ -219,4 +220,4 @@ def test_from_pretrained_then_forward_equals_synthetic(tmp_path):
     ref = _run(_cached_model(cfg), views, flags)
     for k in ("pts3d", "depth", "normals", "camera_params", "camera_poses"):
         assert torch.equal(got[k], ref[k]), k
-        assert rel_l2(got[k].cpu().numpy(), outs[k]) < TOL[k]
+        assert rel_l2(got[k].cpu().numpy(), outs[k]) < GROSS

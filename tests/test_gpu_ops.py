@@ -664,6 +664,30 @@ def test_conv_f16_operand_range(dev, Cin, Cout, ks, Hh, Ww, scale):
             assert _rel(y, full) < 4e-3  # in range: 8-bit mantissa rounding of the activations only
 
 
+@pytest.mark.parametrize("Cin,Cout,ks,Hh,Ww", [(256, 256, 3, 37, 37), (128, 32, 3, 30, 30), (256, 256, 1, 16, 16)])
+def test_conv_f16_staging_keeps_nan(dev, Cin, Cout, ks, Hh, Ww):
+    """The saturating f16 staging must not hide an upstream fault: the reference's fp32 heads return NaN when an activation is NaN;
+    v_med3 alone orders NaN low and would hand the MFMA -65504 — plausible finite garbage.  f2h keeps a NaN a NaN: every output
+    pixel whose 3 x 3 (1 x 1) window holds the NaN input is NaN, every other one is finite."""
+    pad = 1 if ks == 3 else 0
+    g = torch.Generator().manual_seed(Cin + ks)
+    N = 1
+    x = torch.randn(N, Hh, Ww, Cin, generator=g)
+    py, px, pc = Hh // 2, Ww // 3, 5
+    x[0, py, px, pc] = float("nan")
+    x = x.to(dev)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w16 = _t16(w.permute(0, 2, 3, 1).contiguous(), F16).to(dev)
+    y = torch.empty(N, Hh, Ww, Cout, device=dev)
+    assert _lib().wm_op_conv(F16, _p(x), _p(w16), None, None, None, _p(y), N, Hh, Ww, Cin, Cout, ks, 1, pad, 0, 0, s) == 0
+    torch.cuda.synchronize()
+    nan_px = torch.isnan(y).any(-1)[0]
+    want = torch.zeros(Hh, Ww, dtype=torch.bool, device=dev)
+    want[max(py - pad, 0):py + pad + 1, max(px - pad, 0):px + pad + 1] = True
+    assert torch.equal(nan_px, want), f"NaN pixels {int(nan_px.sum())}, expected {int(want.sum())}"
+
+
 @pytest.mark.parametrize("Cin,Cout,Hh,Ww", [(256, 256, 37, 37), (256, 256, 70, 45), (256, 128, 40, 40), (128, 128, 33, 100), (256, 256, 148, 148)])
 def test_conv3x3_wide_pixel_tile(dev, Cin, Cout, Hh, Ww):
     """conv3x3_rs_kernel with 32 x 8 pixel tiles (chosen automatically where it saves a round over the CUs, e.g. 148^2

@@ -124,6 +124,21 @@ def test_no_packed_fp32_instruction_outside_the_gelu_gemm(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_unpacked_gelu_build_has_no_packed_fp32_at_all(tmp_path):
+    """-DWM_UNPACKED_GELU (wm_common.h) is the build for deployments that put several handles' kernels beside each other on one
+    device (wm_share_weights from several threads): with it no kernel of gemm.hip — the one file allowed packed fp32 — holds any."""
+    flags = None
+    for line in open(os.path.join(CSRC, "Makefile")):
+        if line.startswith("CXXFLAGS"):
+            flags = [f.replace("$(ARCH)", "gfx950") for f in line.split("=", 1)[1].split() if not f.startswith("$(")]
+    asm = tmp_path / "gemm_unpacked.s"
+    r = subprocess.run(["hipcc", *flags, "-DWM_UNPACKED_GELU", "-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, "gemm.hip"), "-o", str(asm)],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert not re.search(r"v_pk_(?:mul|fma|add)_f32", open(asm).read())
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 def test_conv3x3_kernels_do_not_spill(tmp_path):
     """The 256-pixel x 256-channel conv tile keeps 128 accumulator registers per lane and prefetches its residual inputs in the
     epilogue: one float4 array too many and hipcc spills (a first form of the LDS-staged epilogue spilled 68 registers)."""
