@@ -779,9 +779,13 @@ int wm_attention_variant(const WmAttnArgs& a) {
   static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
   const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
-  const bool fast_ok = a.unit_flags != nullptr && seg_rows >= 512 && seg_rows % 64 == 0;
-  const bool v3ok = a.dtype == WM_T_BF16 && a.unit_flags != nullptr && seg_rows >= 512 && (seg_rows % 64 == 0 || a.kv_chunks == 1);
-  int qb = forced ? forced : (seg_rows % 64 == 0 ? (a.dtype == WM_T_BF16 ? 7 : 8) : 0);
+  const bool fast_ok = a.unit_flags != nullptr && seg_rows >= 512;   // (a ragged last tile is padded with zero keys)
+  const bool v3ok = a.dtype == WM_T_BF16 && fast_ok;
+  int qb = forced ? forced : (a.dtype == WM_T_BF16 ? 7 : 8);
+  // The short per-frame / DINO sequences (1376 / 1374 keys = 22 tiles per unit): the fast kernels' fixed cost per unit and their
+  // coarser units do not pay below 16 sequences (tools/bench_attn_v4.py, 8 frames: 85 us general (4) vs 87-93 attn_v3 vs 89-94
+  // attn_v4; 32 frames, bf16: 300-312 vs 265-297 attn_v3; f16: 321-337 vs 304-333 attn_v4, left on 4)
+  if (!forced && a.kv_chunks == 1 && a.seq_len <= 2048 && !(a.dtype == WM_T_BF16 && a.q_rows / a.seq_len >= 16)) qb = 4;
   if ((qb == 7 && !v3ok) || (qb == 8 && !fast_ok) || qb == 0) qb = (a.kv_chunks == 1 && a.seq_len <= 2048) ? 4 : 3;
   // piecewise launches (the overlapped K/V gather of a sharded forward) write partials for every unit: kernels 3, 7 and 8 do;
   // a short or ragged local chunk (one view per rank: 1376 keys) would otherwise pick 4
@@ -812,7 +816,7 @@ hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
   if (qb == 7) return launch<WM_T_BF16, 4, 2, 2>(a, s, 3);
   if (qb == 8) {  // attn_v4: 512-row units, one block per CU; the flagged units re-run on 8 waves x 64 rows of the general kernel
-    if (!a.unit_flags || seg_rows % 64 != 0) return hipErrorInvalidValue;
+    if (!a.unit_flags) return hipErrorInvalidValue;
     return a.dtype == WM_T_BF16 ? launch<WM_T_BF16, 8, 2, 2>(a, s, 4) : launch<WM_T_F16, 8, 2, 2>(a, s, 4);
   }
   if (qb == 6) return a.dtype == WM_T_BF16 ? launch_sp<WM_T_BF16, 1>(a, s) : launch_sp<WM_T_F16, 1>(a, s);

@@ -27,9 +27,11 @@
 // K/V tiles stream by LDS-DMA into rings (K 4 deep, V 3 deep: V of tile t is consumed one tile after K of tile t);
 // at the barrier that opens tile t a wave requests K(t+3) and V(t+1): two tile times of flight for every piece, one
 // barrier per tile, counted vmcnt.  f16 P would need the max (5-bit exponent): f16 stays on attention.hip.
-// A key segment that is not a whole number of tiles (the per-frame sequences: 1376 = 21.5 tiles, DINO 1374) is handled in
-// the block's LAST tile only (single-chunk launches): its DMA clamps the row, and the two softmax halves of that tile run a
-// masked variant (P = 0 beyond the last key) — the steady-state loop stays branch-free.
+// A key segment that is not a whole number of tiles (the per-frame sequences: 1376 = 21.5 tiles, DINO 1374; an odd number of
+// views in a cross-view sequence or gathered chunk) gets its last tile PADDED WITH ZERO ROWS by the DMA: a zero key scores
+// S = 0 exactly, P = 2^0 = 1 exactly, its zero V row adds nothing to O, and the epilogue takes the pads out of the row sums
+// again — no masking, no second instantiation, the loop and its 236 registers untouched (round 2's masked instantiation
+// needed one wave per SIMD and lost to the general kernel on exactly the sequences it was for).
 #include "wm_common.h"
 #include "wm_kernels.h"
 
@@ -60,6 +62,14 @@ __device__ __forceinline__ void dma16(const void* sbase, uint32_t voff, uint32_t
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
+// The same piece with a per-lane 64-bit source pointer (ragged last tile: rows beyond the segment come from wm_zero_rows_v3)
+__device__ __forceinline__ void dma16p(const void* g, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+__device__ __attribute__((aligned(128))) const uint4 wm_zero_rows_v3[8] = {};
+
 // sched_group_barrier masks (LLVM SchedGroupMask)
 #ifdef WM_ATTN_STAMPS
 __device__ unsigned long long wm_attn3_stamp_buf[4 * 8192];   // diagnostic build only (see attention_v4.hip)
@@ -69,8 +79,7 @@ __device__ unsigned long long wm_attn3_stamp_buf[4 * 8192];   // diagnostic buil
 #define SG_DSRD 0x100
 #define SG_TRANS 0x400
 
-// RAGGED: the instantiation for segments that are not whole tiles (per-frame sequences); the cross-view instantiation carries
-// none of that code (its register budget is exact: 236 VGPRs, two waves per SIMD, no scratch)
+// (the second template parameter is kept for the launcher's A/B history: both values are the same kernel now)
 template <int MINW, bool RAGGED>
 __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, int* __restrict__ flags) {
   constexpr int QB = 2, QT = 256;
@@ -115,16 +124,17 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const s16x8*)(qptr + ks * 16 + h * 8);
   }
 
-  // ---- K/V segments (seg_rows is a multiple of 64: checked by the launcher)
+  // ---- K/V segments; rem = valid keys of a segment's last tile (0: whole tiles)
   const int seg_rows = p.kv_chunks > 1 ? p.kv_rows_per_chunk : p.seq_len;
   const int seg_off = p.kv_chunks > 1 ? 0 : seq_row0;
-  const int ntpc = (seg_rows + KVB - 1) / KVB;   // a partial last tile only with kv_chunks == 1 (launcher)
+  const int ntpc = (seg_rows + KVB - 1) / KVB;
+  const int rem = seg_rows % KVB;
   const int ntiles = ntpc * p.kv_chunks;
   const u16* Kb = (const u16*)p.K + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
   const int nt = t1 - t0;  // >= 2 (launcher)
-  const int last_valid = (RAGGED && t1 == ntiles) ? seg_rows - (ntpc - 1) * KVB : KVB;   // valid keys of this block's last tile (wave-uniform)
+  const int npad = rem ? (t1 / ntpc - t0 / ntpc) * (KVB - rem) : 0;   // zero keys this block walks (one ragged tile per segment end in [t0, t1))
 
   // DMA: this wave moves pieces {2 wave, 2 wave + 1} of every K tile and of every V tile (source-side permutation builds the
   // XOR-swizzled K rows and the [4 key][32 d] blocked V image, as in attention.hip).  Source = a wave-uniform tile pointer
@@ -148,20 +158,19 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   int kj = j0, vj = j0;        // tile-in-chunk of the next K / V tile
   int kslot = 0, vslot = 0;    // ring slots of those tiles
   int kidx = 0, vidx = 0;      // index (within this block's range) of those tiles
-  // partial last tile: rows beyond the segment are clamped to its last row (their scores are masked / their P is 0)
-  auto clamp_off = [&](bool isv, int i) {
+  // ragged tile of a segment (wave-uniform, once per segment): per-lane pointers, rows >= rem from the zero rows
+  auto pad_ptr = [&](bool isv, int i, const char* src) -> const char* {
     const int pc = wave * 2 + i;
-    int key, d8;
-    if (!isv) { key = pc * 8 + (lane >> 3); d8 = (lane & 7) ^ ((key >> 1) & 7); }
-    else { const int off = pc * 1024 + lane * 16, blk = off >> 8; key = (blk >> 1) * 4 + ((off >> 6) & 3); d8 = (blk & 1) * 4 + ((off >> 4) & 3); }
-    key = key < last_valid ? key : last_valid - 1;
-    return (uint32_t)(key * 64 + d8 * 8) * 2;
+    int key;
+    if (!isv) key = pc * 8 + (lane >> 3);
+    else { const int off = pc * 1024 + lane * 16, blk = off >> 8; key = (blk >> 1) * 4 + ((off >> 6) & 3); }
+    return key < rem ? src + (isv ? voff[i] : koff[i]) : (const char*)wm_zero_rows_v3 + (lane & 7) * 16;
   };
   auto dma_k = [&]() {
     const uint32_t dst = smem_base + kslot * TILE_B + wave * 2048;
-    if (RAGGED && last_valid < KVB && kidx == nt - 1) {  // wave-uniform, once per block
-      dma16(ksrc, clamp_off(false, 0), dst);
-      dma16(ksrc, clamp_off(false, 1), dst + 1024);
+    if (rem && kj == ntpc - 1) {
+      dma16p(pad_ptr(false, 0, ksrc), dst);
+      dma16p(pad_ptr(false, 1, ksrc), dst + 1024);
     } else {
       dma16(ksrc, koff[0], dst);
       dma16(ksrc, koff[1], dst + 1024);
@@ -172,9 +181,9 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   };
   auto dma_v = [&]() {
     const uint32_t dst = smem_base + VBASE + vslot * TILE_B + wave * 2048;
-    if (RAGGED && last_valid < KVB && vidx == nt - 1) {
-      dma16(vsrc, clamp_off(true, 0), dst);
-      dma16(vsrc, clamp_off(true, 1), dst + 1024);
+    if (rem && vj == ntpc - 1) {
+      dma16p(pad_ptr(true, 0, vsrc), dst);
+      dma16p(pad_ptr(true, 1, vsrc), dst + 1024);
     } else {
       dma16(vsrc, voff[0], dst);
       dma16(vsrc, voff[1], dst + 1024);
@@ -263,21 +272,6 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     }
   };
   auto sm = [&](int par) { sm_half(par, 0); sm_half(par, 1); };
-  auto sm_half_masked = [&](int par, int b, int nvalid) {  // the same with P = 0 for the half's keys >= nvalid (last tile of a ragged segment)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      float e[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = 8 * s2 + i, key = (r & 3) + 8 * (r >> 2) + 4 * h;
-        e[i] = key < nvalid ? __builtin_amdgcn_exp2f(st[par][b][r]) : 0.f;
-        lsum[b][i & 1] += e[i];
-      }
-      uint4 u;
-      u.x = pack2bf(e[0], e[1]); u.y = pack2bf(e[2], e[3]); u.z = pack2bf(e[4], e[5]); u.w = pack2bf(e[6], e[7]);
-      pf[par][b][s2] = __builtin_bit_cast(s16x8, u);
-    }
-  };
   // A step is two scheduling regions of 8 MFMA gaps, each gap = 1 MFMA + (1 LDS read) + 2 exp + 3 plain VALU:
   //   region A: QK MFMAs | the 8 V^T fragment reads of THIS step's PV | softmax of q-block 0
   //   region B: PV MFMAs | the 4 K fragment reads of the NEXT step's QK | softmax of q-block 1
@@ -328,8 +322,7 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   // barrier B_j opens step 2j: everybody finished step 2j-1, so K(j-1) and V(j-2) are dead = the slots K(j+3) and V(j+1) go to;
   // the wait leaves only the four youngest pieces (K(j+2), V(j), requested at B_{j-1}) in flight: K(j+1), V(j-1) landed.
   int vs = 0;  // V ring slot of tile j-1
-  auto tile_body = [&](int j, auto masked_c) {
-    constexpr bool MASKED = decltype(masked_c)::value;   // this is the block's last tile and it is partial
+  auto tile_body = [&](int j) {
     if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -354,32 +347,24 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
     // step 2j+1
     qk(1);
     load_v(va, 1);
-    if constexpr (MASKED) sm_half_masked(0, 0, last_valid); else sm_half(0, 0);
+    sm_half(0, 0);
     pipeline8(8);
     __builtin_amdgcn_sched_barrier(0);
     pv(1);
     load_k(kb, 0);   // past the last tile: a dead read of a valid slot (keeps the step branch-free)
-    if constexpr (MASKED) sm_half_masked(0, 1, last_valid); else sm_half(0, 1);
+    sm_half(0, 1);
     pipeline8(4);
     __builtin_amdgcn_sched_barrier(0);
     vs = vs == VRING - 1 ? 0 : vs + 1;
   };
-  const bool ragged = RAGGED && last_valid < KVB;   // wave-uniform
-  if constexpr (RAGGED) {
-    for (int j = 1; j < nt - 1; ++j) tile_body(j, std::false_type{});
-    if (ragged) tile_body(nt - 1, std::true_type{}); else tile_body(nt - 1, std::false_type{});
-  } else {
-    for (int j = 1; j < nt; ++j) tile_body(j, std::false_type{});
-  }
+  for (int j = 1; j < nt; ++j) tile_body(j);
   // ---- epilogue: V(nt-1) landed (the last waits were vmcnt(0) + barrier);
   //      step 2nt: PV(2nt-2) + SM(2nt-1); step 2nt+1: PV(2nt-1)
   {
     const uint32_t va = lds_v(vs);
     load_v(va, 0);
     pv(0);
-    if constexpr (RAGGED) {
-      if (ragged) { sm_half_masked(1, 0, last_valid - 32); sm_half_masked(1, 1, last_valid - 32); } else sm(1);
-    } else sm(1);
+    sm(1);
     __builtin_amdgcn_sched_barrier(0);
     load_v(va, 1);
     pv(1);
@@ -401,6 +386,10 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   for (int b = 0; b < QB; ++b) {
     l[b] = xhalf_sum(lsum[b][0] + lsum[b][1]);
     bad = bad || !(l[b] >= 8.2718061e-25f && l[b] <= 1.2676506e30f);  // [2^-80, 2^100]; NaN fails
+    if (npad) {   // the zero keys of a ragged tile contributed P = 1.0 each: take them out again; if the true sum is lost against them
+      l[b] -= (float)npad;                                       // (below 2^-12 of the pads' sum), the general kernel recomputes the unit
+      bad = bad || !(l[b] >= (float)npad * 2.44140625e-4f);
+    }
   }
   const int any_bad = __any(bad) ? 1 : 0;  // wave-uniform
   __shared__ int bad_sh[4];
@@ -447,10 +436,8 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
 // grid / split decisions are the caller's (attention.hip: the same unit numbering as attn_fwd_kernel<.., 4, 2, ..>)
 hipError_t wm_launch_attention_v3(const WmAttnArgs& a, int grid, int* flags, int minw, hipStream_t s) {
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
-  if (seg_rows % KVB) {
-    if (a.kv_chunks > 1) return hipErrorInvalidValue;   // a partial tile only at the end of a single segment
-    hipLaunchKernelGGL((attn_v3_kernel<1, true>), dim3(grid), dim3(256), 0, s, a, flags);
-  } else if (minw >= 2) hipLaunchKernelGGL((attn_v3_kernel<2, false>), dim3(grid), dim3(256), 0, s, a, flags);
+  if (seg_rows < KVB) return hipErrorInvalidValue;
+  if (minw >= 2) hipLaunchKernelGGL((attn_v3_kernel<2, false>), dim3(grid), dim3(256), 0, s, a, flags);
   else hipLaunchKernelGGL((attn_v3_kernel<1, false>), dim3(grid), dim3(256), 0, s, a, flags);
   return hipGetLastError();
 }

@@ -75,7 +75,10 @@ __device__ __forceinline__ void dma2(const void* sbase, uint32_t voff0, uint32_t
 // cost copies of their own.  Here the "a" / "v" constraints place every operand, the compiler allocates the registers,
 // issues the LDS fragment reads between the statements and owns every wait.
 // Order inside a gap: exp, exp, MFMA, add, add, pack — a transcendental's result is not used by the next VALU instruction
-// (one wait state is required: the MFMA provides it).  What hipcc does not see are the MFMAs' result hazards: every reader of
+// (one wait state is required: the MFMA provides it), and the two exps are the two wait states an MFMA needs behind a compiler
+// instruction that wrote one of its operands just before the statement (a v_accvgpr_write of a Q fragment, a v_mov): hipcc pads
+// nothing in front of a statement.  The bare forms (no softmax beside the MFMA: prologue, drain) open with s_nop 1 for the same
+// reason — without it the f16 prologue read stale Q fragments on some rows of q-block 0 (caught by the op test).  What hipcc does not see are the MFMAs' result hazards: every reader of
 // an MFMA result is >= 16 instructions behind it (the schedule in the header), the epilogue is fenced by s_nops, and the
 // f16 prologue's reads of its first scores are fenced by s_nops too.
 #define WM_SM_HEAD "v_exp_f32 %[e0], %[s0]\n\tv_exp_f32 %[e1], %[s1]\n\t"
@@ -85,8 +88,8 @@ __device__ __forceinline__ void dma2(const void* sbase, uint32_t voff0, uint32_t
 #define WM_SM_IN [s0] "v"(s0), [s1] "v"(s1)
 // O^T += V^T P^T (accumulator in AGPRs), bare and with the softmax quarter
 template <int T> __device__ __forceinline__ void gap_pv(f32x16& acc, const s16x8& a, const s16x8& b) {
-  if constexpr (T == WM_T_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %[c], %[a], %[b], %[c]" : [c] "+a"(acc) : [a] "v"(a), [b] "v"(b));
-  else asm volatile("v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], %[c]" : [c] "+a"(acc) : [a] "v"(a), [b] "v"(b));
+  if constexpr (T == WM_T_BF16) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %[c], %[a], %[b], %[c]" : [c] "+a"(acc) : [a] "v"(a), [b] "v"(b));
+  else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %[c], %[a], %[b], %[c]" : [c] "+a"(acc) : [a] "v"(a), [b] "v"(b));
 }
 template <int T> __device__ __forceinline__ void gap_pv(f32x16& acc, const s16x8& a, const s16x8& b, float s0, float s1, float& l0, float& l1, uint32_t& p, float& e0, float& e1) {
   if constexpr (T == WM_T_BF16)
@@ -97,14 +100,14 @@ template <int T> __device__ __forceinline__ void gap_pv(f32x16& acc, const s16x8
 // S^T = K Q^T: FIRST 1 = first MFMA of a chain with C = 0, 2 = with C = the -m tile (f16), 0 = accumulate.  Q fragments in AGPRs.
 template <int T, int FIRST> __device__ __forceinline__ void gap_qk(f32x16& d, const s16x8& a, const s16x8& bq, const f32x16& c0) {
   if constexpr (FIRST == 1) {
-    if constexpr (T == WM_T_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], 0" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %[d], %[a], %[b], 0" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq));
+    if constexpr (T == WM_T_BF16) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], 0" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %[d], %[a], %[b], 0" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq));
   } else if constexpr (FIRST == 2) {
-    if constexpr (T == WM_T_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[c]" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq), [c] "v"(c0));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %[d], %[a], %[b], %[c]" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq), [c] "v"(c0));
+    if constexpr (T == WM_T_BF16) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[c]" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq), [c] "v"(c0));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %[d], %[a], %[b], %[c]" : [d] "=&v"(d) : [a] "v"(a), [b] "a"(bq), [c] "v"(c0));
   } else {
-    if constexpr (T == WM_T_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]" : [d] "+v"(d) : [a] "v"(a), [b] "a"(bq));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %[d], %[a], %[b], %[d]" : [d] "+v"(d) : [a] "v"(a), [b] "a"(bq));
+    if constexpr (T == WM_T_BF16) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]" : [d] "+v"(d) : [a] "v"(a), [b] "a"(bq));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %[d], %[a], %[b], %[d]" : [d] "+v"(d) : [a] "v"(a), [b] "a"(bq));
   }
 }
 template <int T, int FIRST> __device__ __forceinline__ void gap_qk(f32x16& d, const s16x8& a, const s16x8& bq, const f32x16& c0, float s0, float s1, float& l0, float& l1, uint32_t& p, float& e0, float& e1) {
@@ -119,6 +122,20 @@ template <int T, int FIRST> __device__ __forceinline__ void gap_qk(f32x16& d, co
     else asm volatile(WM_SM_HEAD "v_mfma_f32_32x32x16_f16 %[d], %[a], %[b], %[d]" WM_SM_TAIL_H : [d] "+v"(d), WM_SM_OUT : [a] "v"(a), [b] "a"(bq), WM_SM_IN);
   }
 }
+
+// The same two pieces with per-lane 64-bit source pointers (the ragged last tile of a key segment: rows beyond the segment
+// come from wm_zero_row).  The second pointer is pre-biased by -1024 like voff1m above.
+__device__ __forceinline__ void dma2p(const void* g0, const void* g1m, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(g0), "v"(g1m), "s"(lds_dst) : "memory");
+}
+// 128 B of zeros (+ 1 KiB in front: the -1024 bias of the second piece must stay inside the object)
+__device__ __attribute__((aligned(128))) const uint4 wm_zero_rows_v4[72] = {};
 
 #define SG_VALU 0x002
 #define SG_MFMA 0x008
@@ -180,15 +197,26 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
     for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const s16x8*)(qptr + ks * 16 + h * 8);
   }
 
-  // ---- K/V segments (whole 64-key tiles: checked by the launcher)
+  // Q goes to the accumulator half of the register file here, once (every use is an "a" operand), well before its first MFMA
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+    asm volatile("" :: "a"(qf[b][0]), "a"(qf[b][1]), "a"(qf[b][2]), "a"(qf[b][3]));
+  asm volatile("s_nop 3" ::: "memory");
+
+  // ---- K/V segments.  A segment (a sequence, or one gathered chunk) need not be whole 64-key tiles: its last tile is PADDED WITH
+  // ZERO ROWS by the DMA (rem = its valid keys, 0 = none ragged).  A zero key scores S = 0 exactly, its P is 2^0 (bf16) or
+  // 2^-m (f16) exactly, its zero V row adds nothing to O: the loop runs unmasked and the epilogue takes the pads' P out of the
+  // row sums again (a unit whose true sum is lost against them raises its flag).
   const int seg_rows = p.kv_chunks > 1 ? p.kv_rows_per_chunk : p.seq_len;
   const int seg_off = p.kv_chunks > 1 ? 0 : seq_row0;
-  const int ntpc = seg_rows / KVB;
+  const int ntpc = (seg_rows + KVB - 1) / KVB;
+  const int rem = seg_rows % KVB;
   const int ntiles = ntpc * p.kv_chunks;
   const u16* Kb = (const u16*)p.K + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const u16* Vb = (const u16*)p.V + (size_t)head * p.kv_head_stride * 64 + (size_t)seg_off * 64;
   const int t0 = (int)((long long)split * ntiles / nsplit), t1 = (int)((long long)(split + 1) * ntiles / nsplit);
   const int nt = t1 - t0;  // >= 1
+  const int npad = rem ? (t1 / ntpc - t0 / ntpc) * (KVB - rem) : 0;   // zero keys this block walks (one ragged tile per segment end in [t0, t1))
 
   // DMA: this wave moves pieces {2 wave, 2 wave + 1} of every K tile and of every V tile (source-side permutation: XOR-swizzled
   // K rows, [4 key][32 d] blocked V image, as attention.hip)
@@ -210,8 +238,24 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   int dj = j0;                 // tile-in-chunk of the next tile to request
   int dks = 0, dvs = 0;        // ring slots of that tile
   auto dma_tile = [&]() {      // K and V of one tile: 4 pieces per wave
-    dma2(ksrc, koff[0], koff[1], smem_base + dks * TILE_B + wave * 2048);
-    dma2(vsrc, voff[0], voff[1], smem_base + VBASE + dvs * TILE_B + wave * 2048);
+    if (rem && dj == ntpc - 1) {   // wave-uniform, once per segment: rows >= rem of this tile are zero rows
+      const char* zero = (const char*)wm_zero_rows_v4 + 1024;
+      const char* kp[2]; const char* vp[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pc = wave * 2 + i;
+        const int kkey = pc * 8 + (lane >> 3);
+        const int off = pc * 1024 + lane * 16, blk = off >> 8;
+        const int vkey = (blk >> 1) * 4 + ((off >> 6) & 3);
+        kp[i] = (kkey < rem ? ksrc + koff[i] : zero + (lane & 7) * 16 - (i ? 1024 : 0));
+        vp[i] = (vkey < rem ? vsrc + voff[i] : zero + (lane & 7) * 16 - (i ? 1024 : 0));
+      }
+      dma2p(kp[0], kp[1], smem_base + dks * TILE_B + wave * 2048);
+      dma2p(vp[0], vp[1], smem_base + VBASE + dvs * TILE_B + wave * 2048);
+    } else {
+      dma2(ksrc, koff[0], koff[1], smem_base + dks * TILE_B + wave * 2048);
+      dma2(vsrc, voff[0], voff[1], smem_base + VBASE + dvs * TILE_B + wave * 2048);
+    }
     ksrc += TILE_B; vsrc += TILE_B;
     if (++dj == ntpc) { dj = 0; ksrc += chunk_jump; vsrc += chunk_jump; }
     dks = dks == KRING - 1 ? 0 : dks + 1;
@@ -365,7 +409,10 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
 #pragma unroll
         for (int ks = 1; ks < 4; ++ks) gap_qk<T, 0>(st[b], kfr[ks], qf[b][ks], cinit[b]);
       }
-      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA result -> VALU read (the compiler does not see the asm MFMAs' latency)
+      // MFMA result -> VALU read: the compiler does not see the asm MFMAs' latency, and it may move a register-only reader of
+      // an earlier statement's result ABOVE a fence that does not name that result ("memory" orders loads and stores only): the
+      // score tiles are operands of the fence.  (Without them the row max of q-block 0 was taken right behind its MFMA chain.)
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]));
 #pragma unroll
       for (int b = 0; b < QB; ++b) {
         float mx = st[b][0];
@@ -380,6 +427,8 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) cinit[b][r] = -m_run[b];
     }
+    // the -m tiles are MFMA operands (SrcC) of statements the compiler cannot see into: written here, fenced here
+    asm volatile("s_nop 7" :: "v"(cinit[0]), "v"(cinit[1]), "v"(cinit[2]), "v"(cinit[3]) : "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -416,7 +465,8 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   // ---- drain: step 2nt (softmax + PV of the last step), step 2nt+1 (its q-block 3)
   step(PC_DRAIN1{}, ka, 0, va);
   step(PC_DRAIN2{}, ka, 0, va);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA result -> the epilogue's reads of O (the compiler does not see the asm MFMAs' latency)
+  // MFMA result -> the epilogue's reads of O: the fence names the accumulators, so no read can be scheduled above it
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(ot[0][0]), "+a"(ot[0][1]), "+a"(ot[1][0]), "+a"(ot[1][1]), "+a"(ot[2][0]), "+a"(ot[2][1]), "+a"(ot[3][0]), "+a"(ot[3][1]));
 
 #ifdef WM_ATTN_STAMPS
   if (tid == 0) {
@@ -435,6 +485,11 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
 #pragma unroll
   for (int b = 0; b < QB; ++b) {
     l[b] = xhalf_sum((lsum[b][0] + lsum[b][1]) + (lsum[b][2] + lsum[b][3]));
+    if (npad) {   // take the zero keys' P (2^(0 - m) each, the same v_exp_f32 the loop evaluated) out of the sum again
+      const float pads = (float)npad * (F16 ? __builtin_amdgcn_exp2f(-m_run[b]) : 1.0f);
+      l[b] -= pads;
+      bad |= !(l[b] >= pads * 2.44140625e-4f) ? 8 : 0;   // 2^-12: below that the fp32 sum has lost the true part against the pads
+    }
     if constexpr (F16) {
       float t = 0.f;   // stays 0 iff every O value of the row is finite (x * 0 is NaN for inf and NaN)
 #pragma unroll
@@ -502,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
 // grid / split decisions are the caller's (attention.hip: the unit numbering of attn_fwd_kernel<.., 8, 2, ..>, 512-row units)
 hipError_t wm_launch_attention_v4(const WmAttnArgs& a, int grid, int* flags, hipStream_t s) {
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
-  if (seg_rows % KVB || seg_rows < KVB) return hipErrorInvalidValue;
+  if (seg_rows < KVB) return hipErrorInvalidValue;
   if (a.dtype == WM_T_BF16) hipLaunchKernelGGL((attn_v4_kernel<WM_T_BF16>), dim3(grid), dim3(256), 0, s, a, flags);
   else hipLaunchKernelGGL((attn_v4_kernel<WM_T_F16>), dim3(grid), dim3(256), 0, s, a, flags);
   return hipGetLastError();

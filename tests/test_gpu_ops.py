@@ -345,13 +345,16 @@ def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev, dt=BF16):
 
 
 @pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0),
-                                                     (16, 8, 1376, 1, 0), (16, 3, 1374, 1, 0), (2, 1, 1000, 1, 1), (3, 2, 577, 1, 1)])
+                                                     (16, 8, 1376, 1, 0), (16, 3, 1374, 1, 0), (2, 1, 1000, 1, 1), (3, 2, 577, 1, 1),
+                                                     (3, 1, 4128, 3, 0), (2, 1, 9632, 1, 0)])
 def test_attention_v3_pipelined_no_max_kernel(dev, H, nseq, L, chunks, splits):
     """attention_v3.hip (attn_qb = 7): software-pipelined, no running max.  Same operands -> the general kernel's result up to
     final-rounding flips (2^S / sum 2^S is scale-free, bf16 rounding of P too), fp32 softmax within the bf16 P / O rounding;
     whole units, uniform splits (chunks > 1), the tail split (16 heads x 43 q-tiles = 688 units on 512 slots), 2 sequences, and
     RAGGED sequences — per-frame 1376 = 21.5 key tiles (8 frames x 6 q-tiles x 16 heads = 768 units: tail split in halves),
-    DINO's 1374 (the last tile has 30 keys: half 0 partly, half 1 fully masked), 1000 and 577 rows."""
+    DINO's 1374 (the last tile has 30 keys), 1000 and 577 rows, three gathered chunks of one view each (every chunk ends in a
+    ragged tile) and a 7-view cross-view sequence (150.5 tiles).  Ragged tiles are padded with zero keys by the DMA (P = 1 exactly,
+    V = 0) and the pads are taken out of the row sums in the epilogue: round 3, no masked instantiation any more."""
     L_ = _lib()
     g = torch.Generator().manual_seed(H * 13 + L + chunks)
     R = nseq * L
@@ -411,14 +414,16 @@ def test_attention_v3_out_of_range_rows_are_recomputed(dev, kind):
 
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0),
-                                                     (2, 1, 576, 1, 1), (5, 3, 1024, 1, 0)])
+                                                     (2, 1, 576, 1, 1), (5, 3, 1024, 1, 0),
+                                                     (16, 8, 1376, 1, 0), (16, 3, 1374, 1, 0), (2, 1, 1000, 1, 1), (3, 1, 4128, 3, 0), (2, 1, 9632, 1, 0)])
 def test_attention_v4_one_wave_per_simd(dev, H, nseq, L, chunks, splits, dt):
     """attention_v4.hip (attn_qb = 8): one wave per SIMD, 128 query rows per wave, every MFMA gap a hand-placed asm statement; bf16
     without a running max, f16 with the row max fixed from the first key tile (+ headroom) in the QK chain's initial accumulator.
     Same operands -> the general kernel's result up to final-rounding flips (integer max: the mantissa of P does not depend on it),
     fp32 softmax within the 16-bit P / O rounding.  Whole units, uniform splits, chunked keys, the tail split (16 heads x 22 q-tiles
     = 352 units on 256 slots), several sequences, a 576-key sequence (9 tiles: the shortest pipelines), a last q-tile with 64 of
-    512 rows (576 = 512 + 64)."""
+    512 rows (576 = 512 + 64); ragged segments (per-frame 1376, DINO 1374, 1000 rows, three one-view chunks, 7 views): the last
+    tile of a segment is padded with zero keys (P = 2^0 / 2^-m exactly, V = 0), taken out of the row sums in the epilogue."""
     L_ = _lib()
     g = torch.Generator().manual_seed(H * 13 + L + chunks)
     R = nseq * L

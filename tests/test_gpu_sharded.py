@@ -188,14 +188,14 @@ def test_c5_eight_virtual_ranks_f16_gs_head_cross_rank_prune():
     world, per = 8, 4
     g = torch.Generator().manual_seed(5)
     views = {"img": torch.rand(1, world * per, 3, 518, 518, generator=g).cuda()}
-    single = WorldMirror(arch=WMConfig(), dtype="f16").init_synthetic_weights(preset="refinit").to("cuda:0")
+    single = WorldMirror(arch=WMConfig(enable_gs=True), dtype="f16").init_synthetic_weights(preset="refinit").to("cuda:0")
     ref = single(views)
     torch.cuda.synchronize()
     n_ref = int(ref["splats"]["means"][0].shape[0])
     ref = {k: ref[k].cpu() for k in ("pts3d", "depth", "normals")}
     L = _lib.lib()
     grp = C.c_void_p(L.wm_local_group_create(world))
-    models = [WorldMirror(arch=WMConfig(), dtype="f16").to("cuda:0").share_weights_from(single).shard_local(grp, r, world) for r in range(world)]
+    models = [WorldMirror(arch=WMConfig(enable_gs=True), dtype="f16").to("cuda:0").share_weights_from(single).shard_local(grp, r, world) for r in range(world)]
     res = _run_ranks(models, views, [0, 0, 0])
     for k in ("pts3d", "depth", "normals"):
         got = torch.cat([res[r][k] for r in range(world)], 1).cpu()

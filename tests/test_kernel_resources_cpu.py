@@ -86,6 +86,14 @@ def test_attention_v4_register_file_split_and_clean_loop(tmp_path):
         assert count(r"v_exp_f32") == 128 and count(r"v_add_f32") == 128 and count(r"v_cvt_pk_") == 64, name
         assert count(r"ds_read") == 24, (name, count(r"ds_read"))
         assert count(r"s_nop") <= 20, (name, count(r"s_nop"))
+        assert count(r"v_mov_b") <= 1, (name, "a register copy in front of a statement would need wait states nobody inserts")
+        if "ILi1E" in name:   # f16: the prologue takes the first tile's row maxima from asm MFMA results behind an s_nop fence.  The
+            # fence must NAME the score tiles: a "memory"-only fence let the compiler schedule the v_max of q-block 0 right behind its
+            # MFMA chain (stale reads on ~1 % of the rows; caught by tests/test_gpu_ops.py test_attention_v4_one_wave_per_simd)
+            first_mfma = next(i for i, l in enumerate(lines) if "v_mfma" in l)
+            fence = next(i for i, l in enumerate(lines) if "s_nop 15" in l)
+            assert fence > first_mfma
+            assert not any(re.search(r"v_max", l) for l in lines[first_mfma:fence]), name
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")

@@ -15,12 +15,16 @@ dt = 0 if dt_name == "bf16" else 1
 tdt = torch.bfloat16 if dt == 0 else torch.float16
 variants = [int(x) for x in args] or ([3, 7, 8] if dt == 0 else [3, 8])
 cases = [("global_8v", 16, 8 * 1376, 1, 0), ("global_16v", 16, 16 * 1376, 1, 0), ("global_32v", 16, 32 * 1376, 1, 0),
-         ("sharded_8v_x8chunks", 16, 8 * 1376, 8, 8 * 1376), ("global_2v", 16, 2 * 1376, 1, 0), ("global_7v", 16, 7 * 1376, 1, 0)]
+         ("sharded_8v_x8chunks", 16, 8 * 1376, 8, 8 * 1376), ("global_2v", 16, 2 * 1376, 1, 0), ("global_7v", 16, 7 * 1376, 1, 0),
+         ("sharded_3v_x3chunks", 16, 3 * 1376, 3, 3 * 1376),   # ragged chunks: 64.5 key tiles each
+         ("frame_8x1376", 16, 8 * 1376, 1, -1376), ("dino_8x1374", 16, 8 * 1374, 1, -1374), ("frame_32x1376", 16, 32 * 1376, 1, -1376)]  # Lc < 0: per-frame sequences of -Lc rows
 if os.environ.get("CASES"):
     cases = [c for c in cases if c[0] in os.environ["CASES"].split(",")]
 spike = os.environ.get("SPIKE", "0") == "1"
 for name, H, M, chunks, Lc in cases:
     Ls = M
+    if Lc < 0:
+        Ls, Lc = -Lc, 0
     g = torch.Generator(device="cpu").manual_seed(1)
     q32 = torch.randn(H, M, 64, generator=g) * 0.125 * 1.4427 * 1.5
     nk = chunks if chunks > 1 else 1
@@ -35,9 +39,9 @@ for name, H, M, chunks, Lc in cases:
     flags = torch.full((int(L.wm_op_attention_flag_count(M, Ls, H)),), 7, device=dev, dtype=torch.int32)
     keys = Ls if chunks == 1 else chunks * Lc
     fl = 4.0 * M * keys * 64 * H
-    # fp32 reference on head 3, a slice of query rows (scores are in log2 units: P = 2^S)
-    hd = 3; rows = torch.arange(0, M, max(1, M // 2048), device=dev)
-    kk = k[:, hd].reshape(-1, 64).float(); vv = v[:, hd].reshape(-1, 64).float()
+    # fp32 reference on head 3, a slice of query rows of the first sequence (scores are in log2 units: P = 2^S)
+    hd = 3; rows = torch.arange(0, Ls, max(1, Ls // 2048), device=dev)
+    kk = k[:, hd].reshape(-1, 64).float()[:keys]; vv = v[:, hd].reshape(-1, 64).float()[:keys]
     S = q[hd][rows].float() @ kk.T
     P = torch.exp2(S - S.max(dim=1, keepdim=True).values)
     ref = (P / P.sum(dim=1, keepdim=True)) @ vv
