@@ -767,10 +767,10 @@ hipError_t wm_launch_attention_combine(const WmAttnArgs& a_in, int slots, hipStr
 }
 
 // Which kernel a launch takes (the attn_qb numbering of the tuning interface), or -1 for an invalid request:
-//   7  attn_v3 (attention_v3.hip): bf16, software-pipelined, no running max, two waves per SIMD, 256-row units
+//   7  attn_v3 (attention_v3.hip): bf16, software-pipelined, no running max, two waves per SIMD, 256-row units: the per-frame
+//      sequences from 16 frames up
 //   8  attn_v4 (attention_v4.hip): one wave per SIMD, 128 query rows per wave, 512-row units; bf16 (no max) and f16 (fixed
-//      integer max in the QK chain's initial accumulator) — the default for f16, whose only other kernel is the general one
-//      (tools/bench_attn_v4.py, 32 views: 1151-1156 vs 1026-1031 TF/s; bf16: 1243 vs attn_v3's 1235-1238, a tie)
+//      integer max in the QK chain's initial accumulator): every long (cross-view) sequence
 //   3  general kernel (integer running max), 64 rows per wave at 2 waves / SIMD: everything else on long sequences, and every
 //      piecewise (force_partial) launch that is not 7 / 8
 //   4  general kernel, 32 rows per wave at 3 waves / SIMD: the short per-frame / DINO sequences
@@ -781,11 +781,14 @@ int wm_attention_variant(const WmAttnArgs& a) {
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
   const bool fast_ok = a.unit_flags != nullptr && seg_rows >= 512;   // (a ragged last tile is padded with zero keys)
   const bool v3ok = a.dtype == WM_T_BF16 && fast_ok;
-  int qb = forced ? forced : (a.dtype == WM_T_BF16 ? 7 : 8);
+  // long (cross-view) sequences: attn_v4 for both types (tools/bench_attn_v4.py, 32 views bf16: 1245-1250 TF/s vs attn_v3's
+  // 1217-1227; 8 views: 1065-1103 vs 1051-1089; f16: 1186-1203 vs the general kernel's 1028-1039)
+  int qb = forced ? forced : 8;
   // The short per-frame / DINO sequences (1376 / 1374 keys = 22 tiles per unit): the fast kernels' fixed cost per unit and their
-  // coarser units do not pay below 16 sequences (tools/bench_attn_v4.py, 8 frames: 85 us general (4) vs 87-93 attn_v3 vs 89-94
-  // attn_v4; 32 frames, bf16: 300-312 vs 265-297 attn_v3; f16: 321-337 vs 304-333 attn_v4, left on 4)
-  if (!forced && a.kv_chunks == 1 && a.seq_len <= 2048 && !(a.dtype == WM_T_BF16 && a.q_rows / a.seq_len >= 16)) qb = 4;
+  // coarser units do not pay below 16 sequences (8 frames: 85 us general (4) vs 87-93 attn_v3 vs 89-94 attn_v4; 32 frames,
+  // bf16: 300-312 vs 265-297 attn_v3 (256-row units suit 1376 rows better than 512-row ones); f16: 321-337 vs 304-333 attn_v4,
+  // left on 4)
+  if (!forced && a.kv_chunks == 1 && a.seq_len <= 2048) qb = (a.dtype == WM_T_BF16 && a.q_rows / a.seq_len >= 16) ? 7 : 4;
   if ((qb == 7 && !v3ok) || (qb == 8 && !fast_ok) || qb == 0) qb = (a.kv_chunks == 1 && a.seq_len <= 2048) ? 4 : 3;
   // piecewise launches (the overlapped K/V gather of a sharded forward) write partials for every unit: kernels 3, 7 and 8 do;
   // a short or ragged local chunk (one view per rank: 1376 keys) would otherwise pick 4

@@ -123,6 +123,19 @@ template <int T, int FIRST> __device__ __forceinline__ void gap_qk(f32x16& d, co
   }
 }
 
+// The four pieces of one tile (K: two, V: two) in one statement.  M0 is written without save / restore: nothing else in this
+// kernel uses it (LDS instructions do not need M0 on gfx9+; tests/test_kernel_resources_cpu.py checks the listing), and the
+// statement that reads M0 is the statement that writes it.
+__device__ __forceinline__ void dma4(const void* kbase, const void* vbase, uint32_t k0, uint32_t k1m, uint32_t v0, uint32_t v1m, uint32_t kdst, uint32_t vdst) {
+  asm volatile(
+      "s_mov_b32 m0, %[kd]\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %[k0], %[kb]\n\t"
+      "global_load_lds_dwordx4 %[k1], %[kb] offset:1024\n\t"
+      "s_mov_b32 m0, %[vd]\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %[v0], %[vb]\n\t"
+      "global_load_lds_dwordx4 %[v1], %[vb] offset:1024"
+      :: [k0] "v"(k0), [k1] "v"(k1m), [v0] "v"(v0), [v1] "v"(v1m), [kb] "s"(kbase), [vb] "s"(vbase), [kd] "s"(kdst), [vd] "s"(vdst) : "memory");
+}
 // The same two pieces with per-lane 64-bit source pointers (the ragged last tile of a key segment: rows beyond the segment
 // come from wm_zero_row).  The second pointer is pre-biased by -1024 like voff1m above.
 __device__ __forceinline__ void dma2p(const void* g0, const void* g1m, uint32_t lds_dst) {
@@ -235,10 +248,14 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   const int c0 = t0 / ntpc, j0 = t0 - c0 * ntpc;
   const char* ksrc = (const char*)(Kb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);  // next tile (wave-uniform)
   const char* vsrc = (const char*)(Vb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);
-  int dj = j0;                 // tile-in-chunk of the next tile to request
-  int dks = 0, dvs = 0;        // ring slots of that tile
-  auto dma_tile = [&]() {      // K and V of one tile: 4 pieces per wave
-    if (rem && dj == ntpc - 1) {   // wave-uniform, once per segment: rows >= rem of this tile are zero rows
+  int dleft = ntpc - j0;       // tiles left in the segment the next request falls into (the last one is the ragged one, if any)
+  const int dleft_ragged = rem ? 1 : -1;   // value of dleft at which the next request is a ragged tile (never, for whole tiles)
+  const uint32_t wbase = __builtin_amdgcn_readfirstlane(smem_base + wave * 2048);   // this wave's share of a ring slot
+  // K and V of one tile into ring slot SL (the rings run in lockstep): 4 pieces per wave, one statement; the slot is static
+  // (the tile loop is unrolled over the ring), so the destinations are constants added to one SGPR
+  auto dma_tile = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot_c)::value;
+    if (dleft == dleft_ragged) {   // wave-uniform, once per segment: rows >= rem of this tile are zero rows
       const char* zero = (const char*)wm_zero_rows_v4 + 1024;
       const char* kp[2]; const char* vp[2];
 #pragma unroll
@@ -250,23 +267,24 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
         kp[i] = (kkey < rem ? ksrc + koff[i] : zero + (lane & 7) * 16 - (i ? 1024 : 0));
         vp[i] = (vkey < rem ? vsrc + voff[i] : zero + (lane & 7) * 16 - (i ? 1024 : 0));
       }
-      dma2p(kp[0], kp[1], smem_base + dks * TILE_B + wave * 2048);
-      dma2p(vp[0], vp[1], smem_base + VBASE + dvs * TILE_B + wave * 2048);
+      dma2p(kp[0], kp[1], wbase + SL * TILE_B);
+      dma2p(vp[0], vp[1], wbase + VBASE + SL * TILE_B);
     } else {
-      dma2(ksrc, koff[0], koff[1], smem_base + dks * TILE_B + wave * 2048);
-      dma2(vsrc, voff[0], voff[1], smem_base + VBASE + dvs * TILE_B + wave * 2048);
+      dma4(ksrc, vsrc, koff[0], koff[1], voff[0], voff[1], wbase + SL * TILE_B, wbase + VBASE + SL * TILE_B);
     }
     ksrc += TILE_B; vsrc += TILE_B;
-    if (++dj == ntpc) { dj = 0; ksrc += chunk_jump; vsrc += chunk_jump; }
-    dks = dks == KRING - 1 ? 0 : dks + 1;
-    dvs = dvs == VRING - 1 ? 0 : dvs + 1;
+    if (__builtin_expect(--dleft == 0, 0)) {   // next segment (the empty statement keeps this a branch: if-converted it is 12 scalar
+      asm volatile("" ::: "memory");          // instructions on every tile)
+      dleft = ntpc; ksrc += chunk_jump; vsrc += chunk_jump;
+    }
   };
 
   f32x16 ot[QB][2];
   f32x16 st[QB];         // scores of one 32-key step, per q-block
   s16x8 pf[QB][2];       // packed P of one step, per q-block and 16-key group
   float lsum[QB][4];
-  float et[4] = {0.f, 0.f, 0.f, 0.f};   // exp scratch of even / odd gaps
+  float eA0 = 0.f, eA1 = 0.f, eB0 = 0.f, eB1 = 0.f;   // exp scratch of even / odd gaps (four scalars: as an array the compiler
+                                                      // keeps one pair in a 64-bit register and pads a wait state in front of every statement using it)
   f32x16 cinit[QB];      // f16: -m broadcast (the QK chain's initial accumulator)
   float m_run[QB];
 #pragma unroll
@@ -321,60 +339,71 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   // The row sums run in four chains per q-block (two per gap, alternating) and the exp results go through two alternating
   // pairs of scratch registers (read-write operands, so that they stay distinct): consecutive statements share no register
   // one writes (hipcc pads a wait state between statements that do).
-  auto group = [&](auto mm_c, auto sm_c, auto ds_c, int b, int sb, int s2, const uint32_t (&ka)[4], int kh, uint32_t va) {
+  // Softmax order: a q-block's 32 scores per lane are 2 x 4 packed words (s2 = 16-key group, w = word).  The first group of a
+  // q-block (half 0) visits (s2, w) = (0,0) (1,0) (0,1) (1,1), the second (half 1) words 2 and 3: consecutive statements then
+  // write words of DIFFERENT packed fragments.  (Words w and w+1 of one fragment are the halves of a 64-bit register pair: hipcc
+  // treats the second half's definition as a read of the pair and pads a wait state behind the statement that wrote the first.)
+  uint32_t pw[QB][2][4];
+  auto group = [&](auto mm_c, auto sm_c, auto ds_c, auto b_c, auto sb_c, auto half_c, auto slot_c, int kh) __attribute__((always_inline)) {
     constexpr int MM = decltype(mm_c)::value, DS = decltype(ds_c)::value;
+    constexpr int b = decltype(b_c)::value, sb = decltype(sb_c)::value, half = decltype(half_c)::value;   // (compile-time: register arrays)
+    constexpr uint32_t KOFF = decltype(slot_c)::value * TILE_B;   // ring offsets fold into the ds_read offset fields
+    const uint32_t va = vaddr0 + KOFF;
     constexpr bool SM = decltype(sm_c)::value;
     constexpr int LC = 2;             // four row-sum chains (alternating pairs)
-    uint32_t u[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float s0 = st[sb][8 * s2 + 2 * i], s1 = st[sb][8 * s2 + 2 * i + 1];
+      const int s2 = i & 1, w = 2 * half + (i >> 1);
+      const float s0 = st[sb][8 * s2 + 2 * w], s1 = st[sb][8 * s2 + 2 * w + 1];
+      uint32_t u = 0;
       if constexpr (MM == 1 && SM) {
-        if (i == 0) gap_qk<T, F16 ? 2 : 1>(st[b], kfr[0], qf[b][0], cinit[b], s0, s1, lsum[sb][LC * (i & 1)], lsum[sb][LC * (i & 1) + 1], u[i], et[2 * (i & 1)], et[2 * (i & 1) + 1]);
-        else gap_qk<T, 0>(st[b], kfr[i], qf[b][i], cinit[b], s0, s1, lsum[sb][LC * (i & 1)], lsum[sb][LC * (i & 1) + 1], u[i], et[2 * (i & 1)], et[2 * (i & 1) + 1]);
+        if (i == 0) gap_qk<T, F16 ? 2 : 1>(st[b], kfr[0], qf[b][0], cinit[b], s0, s1, lsum[sb][LC * (i & 1)], lsum[sb][LC * (i & 1) + 1], u, (i & 1) ? eB0 : eA0, (i & 1) ? eB1 : eA1);
+        else gap_qk<T, 0>(st[b], kfr[i], qf[b][i], cinit[b], s0, s1, lsum[sb][LC * (i & 1)], lsum[sb][LC * (i & 1) + 1], u, (i & 1) ? eB0 : eA0, (i & 1) ? eB1 : eA1);
       } else if constexpr (MM == 1) {
         if (i == 0) gap_qk<T, F16 ? 2 : 1>(st[b], kfr[0], qf[b][0], cinit[b]);
         else gap_qk<T, 0>(st[b], kfr[i], qf[b][i], cinit[b]);
       } else if constexpr (MM == 2 && SM) {
-        gap_pv<T>(ot[b][i & 1], vfr[i >> 1][i & 1], pf[b][i >> 1], s0, s1, lsum[sb][LC * (i & 1)], lsum[sb][LC * (i & 1) + 1], u[i], et[2 * (i & 1)], et[2 * (i & 1) + 1]);
+        gap_pv<T>(ot[b][i & 1], vfr[i >> 1][i & 1], pf[b][i >> 1], s0, s1, lsum[sb][LC * (i & 1)], lsum[sb][LC * (i & 1) + 1], u, (i & 1) ? eB0 : eA0, (i & 1) ? eB1 : eA1);
       } else if constexpr (MM == 2) {
         gap_pv<T>(ot[b][i & 1], vfr[i >> 1][i & 1], pf[b][i >> 1]);
       } else if constexpr (SM) {   // prologue only: no MFMA beside the softmax
         const float e0 = __builtin_amdgcn_exp2f(s0), e1 = __builtin_amdgcn_exp2f(s1);
         lsum[sb][LC * (i & 1)] += e0; lsum[sb][LC * (i & 1) + 1] += e1;
-        u[i] = pack2t<T>(e0, e1);
+        u = pack2t<T>(e0, e1);
       }
-      if constexpr (DS == 1) kfn[i] = read_k(ka[i], kh);
+      if constexpr (SM) pw[sb][s2][w] = u;
+      if constexpr (DS == 1) kfn[i] = read_k(kaddr0[i] + KOFF, kh);
       if constexpr (DS == 2 || DS == 5) { if (i < 3) vnx[DS - 2 + i] = read_v(va, kh, DS - 2 + i); }
       if constexpr (DS == 8) { if (i < 2) vnx[6 + i] = read_v(va, kh, 6 + i); }
     }
-    if constexpr (SM) pf[sb][s2] = __builtin_bit_cast(s16x8, make_uint4(u[0], u[1], u[2], u[3]));
+    if constexpr (SM) {
+      if constexpr (half == 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) pf[sb][s2] = __builtin_bit_cast(s16x8, make_uint4(pw[sb][s2][0], pw[sb][s2][1], pw[sb][s2][2], pw[sb][s2][3]));
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto lds_k = [&](uint32_t (&ka)[4], uint32_t off) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { ka[ks] = kaddr0[ks] + off; asm volatile("" : "+v"(ka[ks])); }
-  };
-  auto lds_v = [&](uint32_t off) { uint32_t va = vaddr0 + off; asm volatile("" : "+v"(va)); return va; };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-  // One step (the header's table).  ka / kh: address and half of this step's K fragments; va: that of this step's V^T fragments
-  // (same tile, same half): they are read during this step's QK groups into a second register set — the reads also separate the
+  // One step (the header's table) on the half kh of the tile in ring slot SL: this step's K fragments, and this step's V^T
+  // fragments (same tile, same half), which are read during the QK groups into a second register set — the reads also separate the
   // statements of the QK chains — and become the operands of the next step's PV groups.
-  auto step = [&](auto parts_c, const uint32_t (&ka)[4], int kh, uint32_t va) {
+  auto step = [&](auto parts_c, auto slot_c, int kh) __attribute__((always_inline)) {
     constexpr int PARTS = decltype(parts_c)::value;
     using SMc = std::integral_constant<bool, (PARTS & P_SM) != 0>;
     constexpr bool QK = (PARTS & P_QK) != 0, PV = (PARTS & P_PV) != 0;
     using MQ = std::integral_constant<int, QK ? 1 : 0>; using MP = std::integral_constant<int, PV ? 2 : 0>;
-    group(std::integral_constant<int, (PARTS & P_QKB3) ? 1 : 0>{}, SMc{}, std::integral_constant<int, QK ? 1 : 0>{}, 3, 0, 0, ka, kh, va);   // G0
-    group(std::integral_constant<int, (PARTS & P_PVB3) ? 2 : 0>{}, SMc{}, I0{}, 3, 0, 1, ka, kh, va);                                        // G1
+    using B0 = I0; using B1 = I1; using B2 = I2; using B3 = std::integral_constant<int, 3>;
+    group(std::integral_constant<int, (PARTS & P_QKB3) ? 1 : 0>{}, SMc{}, std::integral_constant<int, QK ? 1 : 0>{}, B3{}, B0{}, I0{}, slot_c, kh);   // G0
+    group(std::integral_constant<int, (PARTS & P_PVB3) ? 2 : 0>{}, SMc{}, I0{}, B3{}, B0{}, I1{}, slot_c, kh);                                        // G1
     if constexpr (QK) k_next();
     if constexpr ((PARTS & (P_PV | P_PVB3)) != 0) v_next();
-    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 2 : 0>{}, 0, 1, 0, ka, kh, va);   // G2
-    group(MP{}, SMc{}, I0{}, 0, 1, 1, ka, kh, va);                                        // G3
-    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 5 : 0>{}, 1, 2, 0, ka, kh, va);   // G4
-    group(MP{}, SMc{}, I0{}, 1, 2, 1, ka, kh, va);                                        // G5
-    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 8 : 0>{}, 2, 3, 0, ka, kh, va);   // G6
-    group(MP{}, SMc{}, I0{}, 2, 3, 1, ka, kh, va);                                        // G7
+    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 2 : 0>{}, B0{}, B1{}, I0{}, slot_c, kh);   // G2
+    group(MP{}, SMc{}, I0{}, B0{}, B1{}, I1{}, slot_c, kh);                                        // G3
+    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 5 : 0>{}, B1{}, B2{}, I0{}, slot_c, kh);   // G4
+    group(MP{}, SMc{}, I0{}, B1{}, B2{}, I1{}, slot_c, kh);                                        // G5
+    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 8 : 0>{}, B2{}, B3{}, I0{}, slot_c, kh);   // G6
+    group(MP{}, SMc{}, I0{}, B2{}, B3{}, I1{}, slot_c, kh);                                        // G7
   };
   using PC_FIRST = std::integral_constant<int, P_QK>;
   using PC_SECOND = std::integral_constant<int, P_QKB3 | P_QK | P_SM | P_PV>;
@@ -387,12 +416,12 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
 #endif
 
   // ---- prologue: tiles 0 and 1 requested, tile 0 landed; then tile 2 requested
-  dma_tile();
-  if (nt > 1) { dma_tile(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  dma_tile(I0{});
+  if (nt > 1) { dma_tile(I1{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if (nt > 2) dma_tile();
+  if (nt > 2) dma_tile(I2{});
   __builtin_amdgcn_sched_barrier(0);
 
   if constexpr (F16) {
@@ -437,34 +466,33 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
 
-  // steps 0 and 1 (tile 0)
-  uint32_t kso = 0, vso = 0;   // ring offsets of the current tile
-  uint32_t ka[4], va;
-  lds_k(ka, 0);
-  va = lds_v(0);
-  __builtin_amdgcn_sched_barrier(0);
-  step(PC_FIRST{}, ka, 0, va);
-  step(PC_SECOND{}, ka, 1, va);
+  // steps 0 and 1 (tile 0, ring slot 0)
+  step(PC_FIRST{}, I0{}, 0);
+  step(PC_SECOND{}, I0{}, 1);
 
-  // ---- tiles 1 .. nt-1.  Barrier B_j opens step 2j: every wave has finished step 2j-1, so K(j-1) (fragments in registers) and
-  // V(j-2) are dead = the ring slots tile j+2 goes to; the wait leaves only the four youngest pieces (tile j+1) in flight.
-  for (int j = 1; j < nt; ++j) {
+  // ---- tiles 1 .. nt-1, unrolled over the ring (tile j sits in slot j % 3: every LDS address of the loop is a constant).
+  // Barrier B_j opens step 2j: every wave has finished step 2j-1, so tile j-1 is dead (its fragments are in registers) = the ring
+  // slot tile j+2 goes to; the wait leaves only the four youngest pieces (tile j+1) in flight.
+  auto tile_at = [&](auto slot_c, int j) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot_c)::value;
     if (j + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (j + 2 < nt) dma_tile();
-    kso = kso == (KRING - 1) * TILE_B ? 0 : kso + TILE_B;
-    vso = vso == (VRING - 1) * TILE_B ? 0 : vso + TILE_B;
-    lds_k(ka, kso);
-    va = lds_v(vso);
+    if (j + 2 < nt) dma_tile(std::integral_constant<int, (SL + 2) % 3>{});
     __builtin_amdgcn_sched_barrier(0);
-    step(PC_FULL{}, ka, 0, va);   // step 2j  : tile j half 0
-    step(PC_FULL{}, ka, 1, va);   // step 2j+1: tile j half 1
+    step(PC_FULL{}, slot_c, 0);
+    step(PC_FULL{}, slot_c, 1);
+  };
+  int j = 1;
+  for (; j + 2 < nt; j += 3) { tile_at(I1{}, j); tile_at(I2{}, j + 1); tile_at(I0{}, j + 2); }
+  if (j < nt) {
+    tile_at(I1{}, j);
+    if (j + 1 < nt) tile_at(I2{}, j + 1);
   }
   // ---- drain: step 2nt (softmax + PV of the last step), step 2nt+1 (its q-block 3)
-  step(PC_DRAIN1{}, ka, 0, va);
-  step(PC_DRAIN2{}, ka, 0, va);
+  step(PC_DRAIN1{}, I0{}, 0);
+  step(PC_DRAIN2{}, I0{}, 0);
   // MFMA result -> the epilogue's reads of O: the fence names the accumulators, so no read can be scheduled above it
   asm volatile("s_nop 15\n\ts_nop 15" : "+a"(ot[0][0]), "+a"(ot[0][1]), "+a"(ot[1][0]), "+a"(ot[1][1]), "+a"(ot[2][0]), "+a"(ot[2][1]), "+a"(ot[3][0]), "+a"(ot[3][1]));
 

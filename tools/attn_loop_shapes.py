@@ -7,7 +7,7 @@ import ctypes as C, glob, json, os, sys, threading, time
 import numpy as np
 import torch
 SEC = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
-L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libattn_loop_shapes.so"))
+L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", os.environ.get("LOOP_LIB", "libattn_loop_shapes.so")))
 dev = torch.device("cuda:0")
 p = lambda t: C.c_void_p(t.data_ptr())
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -62,9 +62,10 @@ def phase(shape):
         if v: pw[c] = sum(v) / len(v) / 1e6
     mine = max(pw, key=pw.get) if pw else None
     fq = [r[(mine, 'freq1_input')] / 1e6 for r in rows if mine and (mine, 'freq1_input') in r]
-    return {"shape": "32x32x16" if shape == 0 else "16x16x32 (two per gap)", "ms": round(ms, 3), "tflops": round(FLOP / ms / 1e9), "in_kernel_clock_mhz_median": round(float(np.median(clk)), 1),
+    return {"shape": ["32x32x16 + softmax mix", "16x16x32 (two per gap) + softmax mix", "32x32x16 bare MFMA loop", "16x16x32 bare MFMA loop (two per gap)"][shape], "ms": round(ms, 3), "tflops": round(FLOP / ms / 1e9), "in_kernel_clock_mhz_median": round(float(np.median(clk)), 1),
             "cycles_per_gap_median": round(float(np.median(cpg)), 2), "board_W": round(pw[mine], 1) if mine else None, "hwmon_sclk_mhz": round(sum(fq) / len(fq), 1) if fq else None}
 
-for rnd in range(2):
-    for shape in (0, 1):
+SHAPES = [int(x) for x in os.environ.get("SHAPES", "0,1,2,3").split(",")]
+for rnd in range(int(os.environ.get("ROUNDS", "2"))):
+    for shape in SHAPES:
         print(json.dumps({"round": rnd, **phase(shape)}), flush=True)
