@@ -97,6 +97,37 @@ def cpu_baseline(cfg, H, W, budget_views=8):
             "sample": f"{budget_views} view(s) x {H}x{W}, full architecture, fp32 torch-CPU oracle, {dt:.1f} s"}
 
 
+def fixture_parity(m, dev):
+    """Parity of THE BUILD THAT WAS JUST TIMED against the reference itself, so that the headline number and its tolerance travel
+    together: the committed fixture tests/golden/refinit_full_8v_518_noprior.npz holds the REFERENCE's fp32 outputs (written by
+    oracle/gen_golden.py from /root/reference, every 8th pixel + fp64 checksums) for BASELINE C2's own input (seed 1234) on the
+    "refinit" weight preset (the reference's init statistics).  The model's weights are swapped for that preset on the live handle,
+    one forward is run, and rel-L2 against the reference is reported for the dense outputs (north_star: point maps < 1e-3).  Data
+    only is read here (no oracle, no reference code)."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "refinit_full_8v_518_noprior.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path, allow_pickle=False)
+    g = json.loads(str(z["regen_img"]))
+    img = torch.rand(*g["shape"], generator=torch.Generator().manual_seed(int(g["seed"])))
+    if abs(float(img.double().sum()) - float(z["sum_in_img"])) > 1e-6 * img.numel():
+        return {"error": "regenerated input differs from the fixture's"}
+    log("parity leg: refinit weights")
+    m.init_synthetic_weights(preset="refinit")
+    out = m({"img": img.to(dev)}, [0, 0, 0])
+    torch.cuda.synchronize(dev)
+    sub = int(z["subsample"])
+    res = {}
+    for k in ("pts3d", "depth", "normals"):
+        got = out[k].cpu().numpy()[:, :, ::sub, ::sub].astype(np.float64)
+        ref = z["out_" + k].astype(np.float64)
+        res[k] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    return {"fixture": "tests/golden/refinit_full_8v_518_noprior.npz (reference fp32 outputs on this workload's input, refinit weights)",
+            "rel_l2_vs_reference": {k: float(f"{v:.3e}") for k, v in res.items()}, "tolerance": 1e-3,
+            "within_tolerance": all(v < 1e-3 for v in res.values())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +141,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=8, help="views of the CPU-baseline sample (8 = the C2 workload itself)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the C3 (32 views, priors) leg that follows the timed region at N = 1")
+    ap.add_argument("--no-parity", action="store_true", help="skip the committed-fixture parity leg that follows the timed region at N = 1")
     ap.add_argument("--tiny", action="store_true", help="scaled-down architecture (plumbing check only)")
     ap.add_argument("--gs", action="store_true", help="3D-Gaussian head on (BASELINE config C5's flag set with --dtype f16; rasterisation not run, voxel merge off)")
     a = ap.parse_args()
@@ -190,7 +222,20 @@ def main():
             classes[name] = {"ms_total": round(ms, 3), "launches": n, "avg_ms": round(ms / n, 4),
                              "tflops": round(fl[name] / (ms * 1e-3) / 1e12, 1) if ms > 0 else None}
     whole_ms, _ = m.profile_read(4)
+    comm_ms, comm_n = m.profile_read(12)
     m.profile(False)
+    # N > 1: what the first real multi-GPU run needs to explain itself — per rank the cross-view attention time and the time of
+    # the collectives on the queue they ran on (the compute queue unless WM_COMM_OVERLAP=1: then that time is exposed)
+    multi = None
+    if world > 1:
+        mine = {"rank": rank, "global_attention_ms": classes.get("global_attention", {}).get("ms_total"), "allgather_ms": round(comm_ms, 3),
+                "allgather_calls": comm_n, "forward_ms_events": round(whole_ms, 3)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        multi = {"per_rank": allr, "comm_overlap": os.environ.get("WM_COMM_OVERLAP", "0"),
+                 "allgather_bytes_per_rank_per_layer": 2 * 16 * n_local * (cfg.patch_start_idx + (H // cfg.patch_size) * (W // cfg.patch_size)) * 64 * 2,
+                 "note": "allgather_ms = sum over the K|V gathers of the 24 global layers + the camera-token gather, HIP events on the queue the collective ran on; "
+                         "with the gather on the compute queue it is exposed time.  No scaling efficiency is computed here."}
     kernels = dict(classes)                 # per kernel instantiation
     for cls, pre in (("gemm", "gemm_"), ("dpt_conv", "dpt_")):   # the classes as a whole (r01's rows), beside their kernels
         gk = [k for k in classes if k.startswith(pre)]
@@ -236,10 +281,8 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # value is the committed rocprofv3 --pmc measurement of THIS workload (profiles/r01_traffic_n1.json), else null
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic_n1.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic_n1.json")
-        if world == 1 and n_local == 8 and H == 518 and not a.tiny and os.path.exists(tpath):
+        tpath = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic_n1.json", "r02_traffic_n1.json", "r01_traffic_n1.json")) if os.path.exists(p)), "")
+        if world == 1 and n_local == 8 and H == 518 and not a.tiny and tpath:
             traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
@@ -260,6 +303,10 @@ def main():
                 "roofline": roof}
         if north is not None:
             line["north_star"] = north
+        if multi is not None:
+            line["multi_gpu"] = multi
+        if world == 1 and not a.no_parity and not a.tiny and not a.gs and H == 518 and a.dtype == "bf16":
+            line["parity"] = fixture_parity(m, dev)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, H, W, a.cpu_views)
         print(json.dumps(line), flush=True)

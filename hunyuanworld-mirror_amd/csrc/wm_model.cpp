@@ -94,7 +94,7 @@ struct wm_handle {
   hipEvent_t camjoin = nullptr;
   // profiling
   bool prof = false;
-  static constexpr int NKIND = 12;
+  static constexpr int NKIND = 13;
   std::vector<EvPair> ev[NKIND];
   size_t ev_used[NKIND] = {};
 };
@@ -721,6 +721,7 @@ struct ProfScope {
 
 // ---------------------------------------------------------------- collective
 wm_status comm_allgather(wm_handle* h, const void* send, void* recv, size_t bytes, hipStream_t s) {
+  ProfScope ps(h, 12, s);   // timing kind 12: the collective, on the queue it runs on (the compute queue unless WM_COMM_OVERLAP=1)
   Comm& cm = h->comm;
   if (cm.kind == 1) {
     if (ncclAllGather(send, recv, bytes, ncclInt8, cm.nccl, s) != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclAllGather failed");

@@ -126,7 +126,9 @@ wm_status wm_allgather(wm_handle* h, const void* send, void* recv, size_t bytes_
 /* kind: 0 = global attention, 1 = frame+dino attention, 2 = GEMM (epilogues other than the three below), 3 = DPT conv,
  * 4 = whole forward, 5 = GEMM with the fused qkv epilogue, 6 = GEMM with the LayerScale+residual epilogue (proj, fc2),
  * 7 = GEMM with the GELU epilogue (fc1), 8 / 9 = DPT 3x3 convs F -> F on the 4x / 2x pyramid levels, 10 = output_conv1 with the
- * fused resize, 11 = output_conv2 (32 channels) with the fused tail; 3 then holds the remaining convs */
+ * fused resize, 11 = output_conv2 (32 channels) with the fused tail; 3 then holds the remaining convs; 12 = the all-gathers of a
+ * sharded forward (K|V per global layer + the camera tokens), timed on the queue they run on: with the gather on the compute
+ * queue (the default) that is the time the collective is exposed */
 wm_status wm_profile_enable(wm_handle* h, int on);
 wm_status wm_profile_read(wm_handle* h, int kind, double* total_ms, int64_t* launches);
 

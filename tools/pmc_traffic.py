@@ -10,18 +10,24 @@ def rows_of(d, counter):
     return [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
 
 
+def blocks_of(r):
+    wg = r.get("Workgroup_Size") or r.get("Workgroup_Size_X") or "256"
+    return int(r["Grid_Size"]) // max(int(wg), 1)
+
+
 def classify(rows):
     """kernel row name per dispatch (None = not a timed row)"""
-    v3_grids = {int(r["Grid_Size"]) for r in rows if "attn_v3_kernel" in r["Kernel_Name"]}
-    # the v3 launch is followed by a launch of the general kernel that re-runs flagged blocks only (normally none): same block
-    # count, 256 threads per block in both
+    fast = lambda n: "attn_v3_kernel" in n or "attn_v4_kernel" in n   # cross-view attention at 8 views (round 3: attn_v4)
+    fast_blocks = {blocks_of(r) for r in rows if fast(r["Kernel_Name"])}
+    # a fast launch is followed by a launch of the general kernel that re-runs flagged units only (normally none): same block
+    # count (256 threads per block behind attn_v3, 512 behind attn_v4)
     rs_plain = sorted({int(r["Grid_Size"]) for r in rows if re.search(r"conv3x3_rs_kernel<\d+, \d+, \d+, \d+, \d+, 0,", r["Kernel_Name"])}, reverse=True)
     out = []
     for r in rows:
         n, g = r["Kernel_Name"], int(r["Grid_Size"])
         k = None
-        if "attn_v3_kernel" in n: k = "global_attention"
-        elif "attn_fwd_kernel" in n or "attn_sp" in n: k = "global_attention_recheck" if g in v3_grids else "frame_dino_attention"
+        if fast(n): k = "global_attention"
+        elif "attn_fwd_kernel" in n or "attn_sp" in n: k = "global_attention_recheck" if blocks_of(r) in fast_blocks else "frame_dino_attention"
         elif "gemm_pp" in n or "gemm_nt" in n:
             m = re.search(r"gemm_pp2?_kernel<\d+, (\d+)", n)
             e = int(m.group(1)) if m else -1
