@@ -234,6 +234,7 @@ hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s) {
     return wm_launch_conv3x3(a, s);
   }
   if (!no_halo && wm_conv3x3_applicable(a)) return wm_launch_conv3x3(a, s);
+  if (a.in16) return hipErrorInvalidValue;   // only the register-staged 3x3 kernel reads a 16-bit input
   if (a.Cin % 32 != 0 || a.ksize < 1 || a.out16) return hipErrorInvalidValue;  // (16-bit output: register-staged 3x3 kernel only)
   if (a.Ho != (a.Hi + 2 * a.pad - a.ksize) / a.stride + 1 || a.Wo != (a.Wi + 2 * a.pad - a.ksize) / a.stride + 1)
     return hipErrorInvalidValue;

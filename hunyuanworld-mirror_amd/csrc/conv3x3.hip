@@ -391,9 +391,14 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     const int c0 = cc * 64 + ch * 8;
     if (it.in) {
       if constexpr (!UP) {
-        const float* sp = xin + ((size_t)iy * W + ix) * Cin + c0;
-        it.v[0][0] = *(const f32x4*)sp;
-        it.v[0][1] = *(const f32x4*)(sp + 4);
+        if (p.in16) {   // block-uniform: the input is already a 16-bit NHWC tensor of the operand type (RCU conv1 -> conv2): 16 B, no conversion
+          const u16* sp = (const u16*)p.x + ((size_t)n * H * W + (size_t)iy * W + ix) * Cin + c0;
+          it.v[0][0] = __builtin_bit_cast(f32x4, *(const u32x4*)sp);
+        } else {
+          const float* sp = xin + ((size_t)iy * W + ix) * Cin + c0;
+          it.v[0][0] = *(const f32x4*)sp;
+          it.v[0][1] = *(const f32x4*)(sp + 4);
+        }
       } else {
         const float fy = usy * iy, fx = usx * ix;
         int ya = (int)fy, xa = (int)fx;
@@ -422,6 +427,13 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
     const int id = tid + i * 512;
     if (id >= HCH) return;
     const int hr = id >> 3, ch = id & 7;
+    if constexpr (!UP) {
+      if (p.in16) {   // stored as it was loaded (zero outside the image)
+        const u32x4 z = {0, 0, 0, 0};
+        *(u32x4*)(dst + hr * 128 + ((ch ^ swz(hr)) << 4)) = it.in ? __builtin_bit_cast(u32x4, it.v[0][0]) : z;
+        return;
+      }
+    }
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (it.in) {
       if constexpr (!UP) {
@@ -739,5 +751,6 @@ hipError_t wm_launch_conv3x3(const WmConvArgs& a_in, hipStream_t s) {
   a.dbg = 0;
 #endif
   if (a.out16 && !wm_conv3x3_out16_ok(a)) return hipErrorInvalidValue;
+  if (a.in16 && (!wm_conv3x3_out16_ok(a) || a.relu_in)) return hipErrorInvalidValue;   // the register-staged kernel with a plain input only
   return a.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(a, s) : launch_T<WM_T_F16>(a, s);
 }

@@ -166,6 +166,44 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
   }
 }
 
+// The same matrix, INPUT-indexed (round 3): one block per (image, patch row, channel) reads its ps image rows with coalesced
+// full-line loads (lane i at x = 2 i: the whole 2 072-B row of a 518-px image in 5 wave-loads), normalises and rounds once, parks
+// the ps x W tile in LDS and writes it out as gw runs of ps * ps consecutive 16-bit elements (392 B).  The output-indexed kernel
+// above reads the image in 56-B patch-row segments: rocprofv3 showed 81 MB fetched for the 25.8 MB image of 8 views (3.2 x;
+// profiles/r02_hbm_by_kernel.md) — harmless in time (38 us per forward) but not the coalesced image read the design promises.
+// Same arithmetic, same rounding point (every e2e golden runs through it; WM_IM2COL_ROWS=0 selects the output-indexed kernel for an A/B).
+// Needs ps * W * 2 bytes of LDS and an even W.
+template <int T>
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ img, u16* __restrict__ out, int N, int C,
+                                                          int H, int W, int ps, int Kpad, int normalize) {
+  extern __shared__ __attribute__((aligned(16))) u16 tile[];   // [ps][W]
+  const int gh = H / ps, gw = W / ps, K = C * ps * ps;
+  const int c = blockIdx.x % C, py = (blockIdx.x / C) % gh, n = blockIdx.x / (C * gh);
+  const float mean = normalize ? RESNET_MEAN[c] : 0.f, sd = normalize ? RESNET_STD[c] : 1.f;
+  const float* src = img + (((size_t)n * C + c) * H + (size_t)py * ps) * W;   // ps consecutive image rows = one contiguous span
+  const int half = (ps * W) >> 1;
+  for (int i = threadIdx.x; i < half; i += 256) {
+    const float2 v = *(const float2*)(src + 2 * i);
+    const float a = normalize ? (v.x - mean) / sd : v.x, b = normalize ? (v.y - mean) / sd : v.y;
+    *(uint32_t*)(tile + 2 * i) = (uint32_t)f2t<T>(a) | ((uint32_t)f2t<T>(b) << 16);
+  }
+  __syncthreads();
+  const int pp = ps * ps, hp = pp >> 1;   // ps even: a pair (kk, kk + 1) never straddles a patch row
+  u16* dst = out + ((size_t)n * gh * gw + (size_t)py * gw) * Kpad + (size_t)c * pp;
+  for (int i = threadIdx.x; i < gw * hp; i += 256) {
+    const int px = i / hp, kk = 2 * (i - px * hp), ky = kk / ps, kx = kk - ky * ps;
+    *(uint32_t*)(dst + (size_t)px * Kpad + kk) = *(const uint32_t*)(tile + ky * W + px * ps + kx);
+  }
+  if (c == C - 1) {   // zero padding of the rows' tails [K, Kpad)
+    const int tail = (Kpad - K) >> 1;
+    u16* z = out + ((size_t)n * gh * gw + (size_t)py * gw) * Kpad + K;
+    for (int i = threadIdx.x; i < gw * tail; i += 256) {
+      const int px = i / tail, j = i - px * tail;
+      *(uint32_t*)(z + (size_t)px * Kpad + 2 * j) = 0u;
+    }
+  }
+}
+
 // Conv2d(3, C, 7, 1, 3) on the NCHW image as a GEMM (dense_head.py:91-95): row = pixel, col = c*49 + ky*7 + kx
 template <int T>
 __global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ img, u16* __restrict__ out, int N, int H, int W,
@@ -494,6 +532,14 @@ hipError_t wm_launch_im2col(const float* img, void* out, int N, int C, int H, in
                             int dtype, hipStream_t s) {
   const size_t total = (size_t)N * (H / ps) * (W / ps) * Kpad;
   if (!total) return hipSuccess;
+  static const bool rows_env = [] { const char* e = getenv("WM_IM2COL_ROWS"); return !e || atoi(e) != 0; }();
+  const size_t lds = (size_t)ps * W * sizeof(u16);
+  if (rows_env && ps % 2 == 0 && W % 2 == 0 && (C * ps * ps) % 2 == 0 && Kpad % 2 == 0 && lds <= 64 * 1024) {   // input-indexed form (coalesced image reads)
+    const dim3 grid((unsigned)(N * (H / ps) * C));
+    if (dtype == WM_T_BF16) hipLaunchKernelGGL(im2col_rows_kernel<WM_T_BF16>, grid, dim3(256), lds, s, img, (u16*)out, N, C, H, W, ps, Kpad, normalize);
+    else hipLaunchKernelGGL(im2col_rows_kernel<WM_T_F16>, grid, dim3(256), lds, s, img, (u16*)out, N, C, H, W, ps, Kpad, normalize);
+    return hipGetLastError();
+  }
   if (dtype == WM_T_BF16)
     hipLaunchKernelGGL(im2col_kernel<WM_T_BF16>, dim3(grid_for(total)), dim3(256), 0, s, img, (u16*)out, N, C, H, W, ps, Kpad, normalize);
   else

@@ -149,6 +149,8 @@ struct WmConvArgs {
   const float* up_addx; const float* up_addy;
   int out16;           // y is a 16-bit NHWC tensor of the conv's operand type (f16 / bf16) and no fp32 is written: for outputs whose only consumer
                        // rounds them to that type anyway (x2 -> out_conv).  Register-staged 3x3 kernel only: ask wm_conv3x3_out16_ok first
+  int in16;            // x is a 16-bit NHWC tensor of the conv's operand type (the out16 output of the conv before: RCU conv1 -> conv2); same kernels
+                       // as out16 (wm_conv3x3_out16_ok), relu_in must be 0 (the producer applied it)
   int dbg;             // timing experiments only (builds with -DWM_CONV_TIMING_EXPERIMENT; results are wrong): 1 no halo refill, 2 no epilogue, 4 no weight refill
 };
 bool wm_conv3x3_applicable(const WmConvArgs& a);
@@ -203,6 +205,6 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
                               const float* weights, int N, float voxel, float* o_means, float* o_quats, float* o_scales, float* o_opac,
                               float* o_sh, int* K_out, void* workspace, size_t ws_bytes, hipStream_t s);
 
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

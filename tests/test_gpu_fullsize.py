@@ -47,6 +47,23 @@ def test_c2_deterministic(model_and_out):
         assert torch.equal(again[k], out[k]), k                       # no atomics / races anywhere on the path
 
 
+def test_c2_rcu_16bit_intermediates_are_bit_identical(model_and_out):
+    """A ResidualConvUnit's conv1 output has one consumer — conv2's input staging, which applies ReLU and rounds to the f16 operand
+    type.  Round 3: conv1 writes exactly that (relu, 16 bits) and conv2 stages it unconverted (`in16`): a quarter of the bytes written
+    and read, the same values.  `rcu_mid16 = 0` restores the fp32 intermediate: every output must be bit-identical."""
+    from hunyuanworld_mirror_amd import _lib
+    m, img, out = model_and_out
+    L = _lib.lib()
+    assert L.wm_set_tuning(b"rcu_mid16", 0) == 0
+    try:
+        ref = m({"img": img})
+        torch.cuda.synchronize()
+    finally:
+        L.wm_set_tuning(b"rcu_mid16", -1)
+    for k in ("pts3d", "depth", "normals", "pts3d_conf", "depth_conf", "normals_conf", "camera_params"):
+        assert torch.equal(ref[k], out[k]), k
+
+
 def test_c2_single_queue_forward_is_bit_identical_to_the_default(model_and_out):
     """The default forward runs the camera head and the DPT heads on the handle's own queues; WM_HEADS_CONCURRENT=0 (here: the tuning
     key) keeps everything on the caller's stream.  Same kernels, same order within a head: the outputs must be bit-identical, and the
