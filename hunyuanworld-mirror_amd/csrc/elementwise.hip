@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 // Same arithmetic, same rounding point (every e2e golden runs through it; WM_IM2COL_ROWS=0 selects the output-indexed kernel for an A/B).
 // Needs ps * W * 2 bytes of LDS and an even W.
 template <int T>
-__global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ img, u16* __restrict__ out, int N, int C,
+WM_NO_PACKED_FP32 __global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ img, u16* __restrict__ out, int N, int C,
                                                           int H, int W, int ps, int Kpad, int normalize) {
   extern __shared__ __attribute__((aligned(16))) u16 tile[];   // [ps][W]
   const int gh = H / ps, gw = W / ps, K = C * ps * ps;

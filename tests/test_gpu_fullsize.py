@@ -192,15 +192,19 @@ def test_c4_shapes_eight_virtual_ranks(model_and_out):
         for r in range(1, world):
             assert torch.equal(res[r]["camera_params"], res[0]["camera_params"])  # computed redundantly on every rank
         return out
-    a = sharded()
-    b = sharded()
+    # the opt-in overlapped form first (WM_COMM_OVERLAP=1): the K/V all-gather on the communication queue under the attention over
+    # the local keys (three partial launches per layer: own chunk | chunks before | chunks after, + one combine pass)
+    assert L.wm_set_tuning(b"comm_overlap", 1) == 0
+    try:
+        a = sharded()
+        b = sharded()
+    finally:
+        L.wm_set_tuning(b"comm_overlap", -1)
     for k in a:
         assert torch.isfinite(a[k]).all(), k
         assert torch.equal(a[k], b[k]), k
     del b
-    # `a` ran the product default: the K/V all-gather on the communication queue under the attention over the local keys (three
-    # partial launches per layer: own chunk | chunks before | chunks after, + one combine pass).  The same with the gather on the
-    # compute queue and one attention launch over the 8 gathered chunks (WM_COMM_OVERLAP=0):
+    # the product default since round 3: the gather on the compute queue and one attention launch over the 8 gathered chunks
     assert L.wm_set_tuning(b"comm_overlap", 0) == 0
     try:
         c1 = sharded()

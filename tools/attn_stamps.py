@@ -34,7 +34,7 @@ for nv in views:
     def run():
         assert L.wm_op_attention_ex(dt, p(q), p(k), p(v), p(o), H, M, M, 1, 0, 0, p(po), p(pml), p(flags), s) == 0
     for qb, fn, rows, mf_tile in ((7, "wm_debug_attn3_stamps", 256, 32), (8, "wm_debug_attn_stamps", 512, 64)):
-        if qb == 7 and dt != 0:
+        if (qb == 7 and dt != 0) or os.environ.get("STAMP_QB", str(qb)) != str(qb):
             continue
         assert L.wm_set_tuning(b"attn_qb", qb) == 0
         t0 = time.time(); n = 0

@@ -20,6 +20,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #ifndef ORDER
 #define ORDER 0
 #endif
+#ifndef XOR_SINK
+#define XOR_SINK 0
+#endif
 #define SM_HEAD "v_exp_f32 %[e0], %[s0]\n\tv_exp_f32 %[e1], %[s1]\n\t"
 #define SM_OUT [l0] "+v"(l0), [l1] "+v"(l1), [p] "=v"(p), [e0] "+v"(e0), [e1] "+v"(e1)
 #define SM_IN [s0] "v"(s0), [s1] "v"(s1)
@@ -45,6 +48,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define GAP32(M) EXP0 "v_mov_b32 %[e1], %[s1]\n\t" M "\n\t" ADD0 ADD1 PACK
 #elif ORDER == 7   // pricing: no MFMA
 #define GAP32(M) EXP0 EXP1 ADD0 ADD1 PACK
+#elif ORDER == 9   // pricing: consumers of the exp results replaced by independent moves
+#define GAP32(M) EXP0 EXP1 M "\n\tv_mov_b32 %[l0], %[s0]\n\tv_mov_b32 %[l1], %[s1]\n\tv_mov_b32 %[p], %[s0]"
+#elif ORDER == 10  // pricing: no transcendental at all
+#define GAP32(M) "v_mov_b32 %[e0], %[s0]\n\tv_mov_b32 %[e1], %[s1]\n\t" M "\n\t" ADD0 ADD1 PACK
+#elif ORDER == 11  // pricing: MFMA + five moves (no dependency between any two instructions of the gap)
+#define GAP32(M) "v_mov_b32 %[e0], %[s0]\n\tv_mov_b32 %[e1], %[s1]\n\t" M "\n\tv_mov_b32 %[l0], %[s0]\n\tv_mov_b32 %[l1], %[s1]\n\tv_mov_b32 %[p], %[s0]"
 #endif
 // ---- 32x32x16: one MFMA per gap
 __device__ __forceinline__ void gap32_first(f32x16& d, const s16x8& a, const s16x8& b, float s0, float s1, float& l0, float& l1, uint32_t& p, float& e0, float& e1) {
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(256, MINW) void loop_kernel(const uint4* __restrict
     q[i] = __builtin_bit_cast(s16x8, ab[((8 + i) * 256 + tid) & 4095]);
   }
   float l[4] = {0.f, 0.f, 0.f, 0.f}, et[4] = {0.f, 0.f, 0.f, 0.f};
-  uint32_t acc_p = 0;
+  uint32_t acc_p = 0, w0 = 0, w1 = 0;
+  s16x8 pf[2] = {a[0], a[1]};
   unsigned long long c0 = 0, r0 = 0;
   if constexpr (SHAPE == 0) {
     f32x16 S[4], O[8];
@@ -148,21 +158,27 @@ __global__ __launch_bounds__(256, MINW) void loop_kernel(const uint4* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
     if (tid == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-#ifdef UNROLL_IT
-#pragma unroll UNROLL_IT
+#ifndef REP
+#define REP 1     // copies of the 32-gap body per loop iteration (prices the taken branch at the loop's end: one wave per SIMD has nobody to hide it)
 #endif
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; it += REP) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {        // per score tile: its 4 k-steps alternate with 4 accumulating MFMAs (consecutive statements share no
+      for (int g4 = 0; g4 < 4 * REP; ++g4) {        // per score tile
+        const int g = g4 & 3;              // its 4 k-steps alternate with 4 accumulating MFMAs (consecutive statements share no
         const int rd = (g + 2) & 3;        // register one of them writes: hipcc pads a wait state between statements that do); exps read the
         uint32_t u[8];                     // tile written two tiles ago
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (i == 0) gap32_first(S[g], a[0], q[0], S[rd][4 * i], S[rd][4 * i + 1], l[0], l[1], u[2 * i], et[0], et[1]);
           else gap32_next(S[g], a[i], q[i], S[rd][4 * i], S[rd][4 * i + 1], l[0], l[1], u[2 * i], et[0], et[1]);
-          gap32_acc(O[2 * g + (i & 1)], b[i], a[i >> 1], S[rd][4 * i + 2], S[rd][4 * i + 3], l[2], l[3], u[2 * i + 1], et[2], et[3]);
+          gap32_acc(O[2 * g + (i & 1)], b[i], pf[i >> 1], S[rd][4 * i + 2], S[rd][4 * i + 3], l[2], l[3], u[2 * i + 1], et[2], et[3]);
         }
+#if XOR_SINK   // rounds 3's first rows: the packed words kept alive by one v_xor per gap (an instruction the attention loop does not have)
         acc_p ^= u[0] ^ u[1] ^ u[2] ^ u[3] ^ u[4] ^ u[5] ^ u[6] ^ u[7];
+#else          // as in attention_v4.hip: the packed words ARE the next tile's MFMA operand, nothing else reads them
+        pf[0] = __builtin_bit_cast(s16x8, make_uint4(u[0], u[2], u[4], u[6]));
+        pf[1] = __builtin_bit_cast(s16x8, make_uint4(u[1], u[3], u[5], u[7]));
+#endif
       }
     }
     if (tid == 0) { c0 = __builtin_amdgcn_s_memtime() - c0; r0 = __builtin_amdgcn_s_memrealtime() - r0; }
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(256, MINW) void loop_kernel(const uint4* __restrict
       for (int r = 0; r < 16; ++r) acc += O[t][r];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc += S[t][3];
-    sink[blockIdx.x * 256 + tid] = acc + l[0] + l[1] + l[2] + l[3] + (float)(acc_p & 3);
+    sink[blockIdx.x * 256 + tid] = acc + l[0] + l[1] + l[2] + l[3] + (float)((acc_p ^ w0 ^ w1 ^ (uint32_t)pf[0][0] ^ (uint32_t)pf[1][1]) & 3);
   } else {
     f32x4 S[16], O[32];
 #pragma unroll
@@ -192,8 +208,13 @@ __global__ __launch_bounds__(256, MINW) void loop_kernel(const uint4* __restrict
         const int rd = (g + 8) & 15;       // score tile read by this pair's exps: written half a step ago
         uint32_t u0, u1;
         gap16_qk(S[g], a[g & 3], q[g & 3], a[(g + 1) & 3], q[(g + 1) & 3], S[rd][0], S[rd][1], l[0], l[1], u0, et[0], et[1]);
-        gap16_acc(O[2 * g], O[2 * g + 1], b[g & 3], b[(g + 2) & 3], a[g & 3], S[rd][2], S[rd][3], l[2], l[3], u1, et[2], et[3]);
+        gap16_acc(O[2 * g], O[2 * g + 1], b[g & 3], b[(g + 2) & 3], pf[0], S[rd][2], S[rd][3], l[2], l[3], u1, et[2], et[3]);
+#if XOR_SINK
         acc_p ^= u0 ^ u1;
+#else
+        if (g & 1) pf[0] = __builtin_bit_cast(s16x8, make_uint4(w0, w1, u0, u1));
+        else { w0 = u0; w1 = u1; }
+#endif
       }
     }
     if (tid == 0) { c0 = __builtin_amdgcn_s_memtime() - c0; r0 = __builtin_amdgcn_s_memrealtime() - r0; }
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(256, MINW) void loop_kernel(const uint4* __restrict
       for (int r = 0; r < 4; ++r) acc += O[t][r];
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc += S[t][3];
-    sink[blockIdx.x * 256 + tid] = acc + l[0] + l[1] + l[2] + l[3] + (float)(acc_p & 3);
+    sink[blockIdx.x * 256 + tid] = acc + l[0] + l[1] + l[2] + l[3] + (float)((acc_p ^ w0 ^ w1 ^ (uint32_t)pf[0][0] ^ (uint32_t)pf[1][1]) & 3);
   }
   if (tid == 0) { stamps[blockIdx.x * 2] = c0; stamps[blockIdx.x * 2 + 1] = r0; }
 }
