@@ -35,6 +35,20 @@
 
 #include <type_traits>
 
+// Timing-only diagnostic variants of the tile loop (stamps build only; the results are WRONG with any bit set): 1 no tile barrier,
+// 2 no LDS fragment reads in the loop, 4 no K/V DMA in the loop, 8 no vmcnt wait in front of the barrier, 16 (LDS-DMA form) only
+// wave 0 requests its pieces.  tools/attn_v4_diag.sh
+#ifndef WM_V4_DIAG
+#define WM_V4_DIAG 0
+#endif
+#ifndef WM_V4_STAGED
+#define WM_V4_STAGED 0   // 1: (bf16) tiles 2.. travel global -> registers -> LDS (buffer_load_dwordx4, ds_write_b128 a tile later) instead of
+#endif                   // by LDS-DMA.  Measured, not adopted: 47.2 vs 46.8 cycles per MFMA, 1 205 vs 1 217 TF/s at 32 views — a 64-lane
+                         // 16-byte VMEM instruction holds a lone wave ~40 cycles whichever kind it is (profiles/r03_attention_ceiling.md)
+#if WM_V4_DIAG && !defined(WM_ATTN_STAMPS)
+#error "WM_V4_DIAG is for the stamps build only"
+#endif
+
 namespace {
 
 constexpr int KVB = 64;
@@ -248,11 +262,33 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   const int c0 = t0 / ntpc, j0 = t0 - c0 * ntpc;
   const char* ksrc = (const char*)(Kb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);  // next tile (wave-uniform)
   const char* vsrc = (const char*)(Vb + (size_t)c0 * p.kv_chunk_stride + (size_t)j0 * KVB * 64);
-  int dleft = ntpc - j0;       // tiles left in the segment the next request falls into (the last one is the ragged one, if any)
-  const int dleft_ragged = rem ? 1 : -1;   // value of dleft at which the next request is a ragged tile (never, for whole tiles)
+  // The request state points at one tile (wave-uniform, always an existing tile of [t0, t1)): dma_advance() moves it on by one
+  int dleft = ntpc - j0;       // tiles left in its segment, itself included (the last one is the ragged one, if any)
+  const int dleft_ragged = rem ? 1 : -1;   // value of dleft at which the tile is a ragged one (never, for whole tiles)
   const uint32_t wbase = __builtin_amdgcn_readfirstlane(smem_base + wave * 2048);   // this wave's share of a ring slot
-  // K and V of one tile into ring slot SL (the rings run in lockstep): 4 pieces per wave, one statement; the slot is static
-  // (the tile loop is unrolled over the ring), so the destinations are constants added to one SGPR
+  // staged form: the tile's segment as two raw-buffer descriptors of seg_rows * 128 bytes (rows beyond the segment read as zeros:
+  // the hardware's range check — which counts the scalar offset, tools/micro/buffer_oob.hip — pads the ragged tile) + the tile's
+  // byte offset in the segment
+  constexpr bool STAGED = WM_V4_STAGED && !F16;   // f16: no registers left for the staged tile (its -m tiles hold 64)
+  const char* segk = (const char*)(Kb + (size_t)c0 * p.kv_chunk_stride);
+  const char* segv = (const char*)(Vb + (size_t)c0 * p.kv_chunk_stride);
+  __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)segk, 0, seg_rows * 128, 0x00020000);
+  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)segv, 0, seg_rows * 128, 0x00020000);
+  int nsoff = j0 * TILE_B;
+  auto dma_advance = [&]() __attribute__((always_inline)) {
+    ksrc += TILE_B; vsrc += TILE_B; nsoff += TILE_B;
+    if (__builtin_expect(--dleft == 0, 0)) {   // next segment (the empty statement keeps this a branch: if-converted it is a dozen
+      asm volatile("" ::: "memory");          // scalar instructions on every tile)
+      dleft = ntpc; ksrc += chunk_jump; vsrc += chunk_jump;
+      if constexpr (STAGED) {
+        nsoff = 0; segk += p.kv_chunk_stride * 2; segv += p.kv_chunk_stride * 2;
+        krs = __builtin_amdgcn_make_buffer_rsrc((void*)segk, 0, seg_rows * 128, 0x00020000);
+        vrs = __builtin_amdgcn_make_buffer_rsrc((void*)segv, 0, seg_rows * 128, 0x00020000);
+      }
+    }
+  };
+  // K and V of the tile into ring slot SL by LDS-DMA (the rings run in lockstep): 4 pieces per wave, one statement; the slot is
+  // static (the tile loop is unrolled over the ring), so the destinations are constants added to one SGPR
   auto dma_tile = [&](auto slot_c) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot_c)::value;
     if (dleft == dleft_ragged) {   // wave-uniform, once per segment: rows >= rem of this tile are zero rows
@@ -272,10 +308,21 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
     } else {
       dma4(ksrc, vsrc, koff[0], koff[1], voff[0], voff[1], wbase + SL * TILE_B, wbase + VBASE + SL * TILE_B);
     }
-    ksrc += TILE_B; vsrc += TILE_B;
-    if (__builtin_expect(--dleft == 0, 0)) {   // next segment (the empty statement keeps this a branch: if-converted it is 12 scalar
-      asm volatile("" ::: "memory");          // instructions on every tile)
-      dleft = ntpc; ksrc += chunk_jump; vsrc += chunk_jump;
+  };
+  // Staged form (bf16; tiles 2 ..): a global_load_lds_dwordx4 holds the issuing wave for ~57 cycles wherever in the tile it stands
+  // (one wave per SIMD: nobody runs meanwhile; 3.6 of the loop's 46.7 cycles per MFMA, profiles/r03_attn_v4_diag.log); a
+  // buffer_load_dwordx4 into registers and a ds_write_b128 a tile later do not.  Tile j's first step writes the staged tile j + 1
+  // into ring slot (j + 1) % 3 (dead since barrier B_j-1) behind the gaps of G1, then requests tile j + 2 behind G3; the compiler
+  // counts these loads itself (builtin loads, plain stores: no hand-counted vmcnt in the loop).  Same lane -> (source, LDS) mapping
+  // as the DMA pieces.  Past the last tile the last tile is requested again and written to a dead slot: no branch around them.
+  uint4 stg[4];                                   // K piece 0, K piece 1, V piece 0, V piece 1 of the staged tile
+  char* const stg_dst = smem + wave * 2048 + lane * 16;
+  int tile_j = 0;                                 // the tile the loop is at (for the group that requests tile_j + 2)
+  auto stage_load = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t o = i < 2 ? koff[i] + (i ? 1024u : 0u) : voff[i - 2] + (i == 3 ? 1024u : 0u);
+      stg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(i < 2 ? krs : vrs, (int)o, nsoff, 0));
     }
   };
 
@@ -344,8 +391,9 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   // write words of DIFFERENT packed fragments.  (Words w and w+1 of one fragment are the halves of a 64-bit register pair: hipcc
   // treats the second half's definition as a read of the pair and pads a wait state behind the statement that wrote the first.)
   uint32_t pw[QB][2][4];
-  auto group = [&](auto mm_c, auto sm_c, auto ds_c, auto b_c, auto sb_c, auto half_c, auto slot_c, int kh) __attribute__((always_inline)) {
-    constexpr int MM = decltype(mm_c)::value, DS = decltype(ds_c)::value;
+  // DM (staged form): 1 = the staged tile's four pieces are written to LDS, one behind each gap; 2 = the next tile is requested.
+  auto group = [&](auto mm_c, auto sm_c, auto ds_c, auto b_c, auto sb_c, auto half_c, auto slot_c, int kh, auto dm_c) __attribute__((always_inline)) {
+    constexpr int MM = decltype(mm_c)::value, DS = decltype(ds_c)::value, DM = decltype(dm_c)::value;
     constexpr int b = decltype(b_c)::value, sb = decltype(sb_c)::value, half = decltype(half_c)::value;   // (compile-time: register arrays)
     constexpr uint32_t KOFF = decltype(slot_c)::value * TILE_B;   // ring offsets fold into the ds_read offset fields
     const uint32_t va = vaddr0 + KOFF;
@@ -372,9 +420,14 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
         u = pack2t<T>(e0, e1);
       }
       if constexpr (SM) pw[sb][s2][w] = u;
-      if constexpr (DS == 1) kfn[i] = read_k(kaddr0[i] + KOFF, kh);
-      if constexpr (DS == 2 || DS == 5) { if (i < 3) vnx[DS - 2 + i] = read_v(va, kh, DS - 2 + i); }
-      if constexpr (DS == 8) { if (i < 2) vnx[6 + i] = read_v(va, kh, 6 + i); }
+      if constexpr (DM == 1)   // the staged tile's piece i -> ring slot (slot + 1) % 3
+        *(uint4*)(stg_dst + ((decltype(slot_c)::value + 1) % 3) * TILE_B + (i >> 1) * VBASE + (i & 1) * 1024) = stg[i];
+      if constexpr (DM == 2) { if (i == 0) { if (tile_j + 2 < nt) dma_advance(); stage_load(); } }
+      if constexpr (!(WM_V4_DIAG & 2)) {
+        if constexpr (DS == 1) kfn[i] = read_k(kaddr0[i] + KOFF, kh);
+        if constexpr (DS == 2 || DS == 5) { if (i < 3) vnx[DS - 2 + i] = read_v(va, kh, DS - 2 + i); }
+        if constexpr (DS == 8) { if (i < 2) vnx[6 + i] = read_v(va, kh, 6 + i); }
+      }
     }
     if constexpr (SM) {
       if constexpr (half == 1) {
@@ -388,22 +441,25 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   // One step (the header's table) on the half kh of the tile in ring slot SL: this step's K fragments, and this step's V^T
   // fragments (same tile, same half), which are read during the QK groups into a second register set — the reads also separate the
   // statements of the QK chains — and become the operands of the next step's PV groups.
-  auto step = [&](auto parts_c, auto slot_c, int kh) __attribute__((always_inline)) {
+  auto step = [&](auto parts_c, auto slot_c, int kh, auto dma_c) __attribute__((always_inline)) {
     constexpr int PARTS = decltype(parts_c)::value;
+    constexpr bool DMA = decltype(dma_c)::value != 0;
+    using D0 = I0; using D1 = std::integral_constant<int, DMA ? 1 : 0>; using D2 = std::integral_constant<int, DMA ? 2 : 0>;
+    using D3 = I0; using D4 = I0;
     using SMc = std::integral_constant<bool, (PARTS & P_SM) != 0>;
     constexpr bool QK = (PARTS & P_QK) != 0, PV = (PARTS & P_PV) != 0;
     using MQ = std::integral_constant<int, QK ? 1 : 0>; using MP = std::integral_constant<int, PV ? 2 : 0>;
     using B0 = I0; using B1 = I1; using B2 = I2; using B3 = std::integral_constant<int, 3>;
-    group(std::integral_constant<int, (PARTS & P_QKB3) ? 1 : 0>{}, SMc{}, std::integral_constant<int, QK ? 1 : 0>{}, B3{}, B0{}, I0{}, slot_c, kh);   // G0
-    group(std::integral_constant<int, (PARTS & P_PVB3) ? 2 : 0>{}, SMc{}, I0{}, B3{}, B0{}, I1{}, slot_c, kh);                                        // G1
+    group(std::integral_constant<int, (PARTS & P_QKB3) ? 1 : 0>{}, SMc{}, std::integral_constant<int, QK ? 1 : 0>{}, B3{}, B0{}, I0{}, slot_c, kh, D0{});   // G0
+    group(std::integral_constant<int, (PARTS & P_PVB3) ? 2 : 0>{}, SMc{}, I0{}, B3{}, B0{}, I1{}, slot_c, kh, D1{});                                        // G1
     if constexpr (QK) k_next();
     if constexpr ((PARTS & (P_PV | P_PVB3)) != 0) v_next();
-    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 2 : 0>{}, B0{}, B1{}, I0{}, slot_c, kh);   // G2
-    group(MP{}, SMc{}, I0{}, B0{}, B1{}, I1{}, slot_c, kh);                                        // G3
-    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 5 : 0>{}, B1{}, B2{}, I0{}, slot_c, kh);   // G4
-    group(MP{}, SMc{}, I0{}, B1{}, B2{}, I1{}, slot_c, kh);                                        // G5
-    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 8 : 0>{}, B2{}, B3{}, I0{}, slot_c, kh);   // G6
-    group(MP{}, SMc{}, I0{}, B2{}, B3{}, I1{}, slot_c, kh);                                        // G7
+    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 2 : 0>{}, B0{}, B1{}, I0{}, slot_c, kh, D0{});   // G2
+    group(MP{}, SMc{}, I0{}, B0{}, B1{}, I1{}, slot_c, kh, D2{});                                        // G3
+    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 5 : 0>{}, B1{}, B2{}, I0{}, slot_c, kh, D0{});   // G4
+    group(MP{}, SMc{}, I0{}, B1{}, B2{}, I1{}, slot_c, kh, D3{});                                        // G5
+    group(MQ{}, SMc{}, std::integral_constant<int, QK ? 8 : 0>{}, B2{}, B3{}, I0{}, slot_c, kh, D0{});   // G6
+    group(MP{}, SMc{}, I0{}, B2{}, B3{}, I1{}, slot_c, kh, D4{});                                        // G7
   };
   using PC_FIRST = std::integral_constant<int, P_QK>;
   using PC_SECOND = std::integral_constant<int, P_QKB3 | P_QK | P_SM | P_PV>;
@@ -417,11 +473,18 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
 
   // ---- prologue: tiles 0 and 1 requested, tile 0 landed; then tile 2 requested
   dma_tile(I0{});
-  if (nt > 1) { dma_tile(I1{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nt > 1) { dma_advance(); dma_tile(I1{}); }
+  if constexpr (STAGED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tiles 0 and 1 (LDS-DMA) have landed; every later tile travels through registers
+  } else {
+    if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if (nt > 2) dma_tile(I2{});
+  if (nt > 2) dma_advance();
+  if constexpr (STAGED) stage_load();            // tile 2 (or the last tile again: written to a slot nobody reads)
+  else { if (nt > 2) dma_tile(I2{}); }
   __builtin_amdgcn_sched_barrier(0);
 
   if constexpr (F16) {
@@ -466,23 +529,48 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
 
+#if WM_V4_DIAG & 2
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kfn[i] = read_k(kaddr0[i], 0);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) vnx[r] = read_v(vaddr0, 0, r);
+#endif
   // steps 0 and 1 (tile 0, ring slot 0)
-  step(PC_FIRST{}, I0{}, 0);
-  step(PC_SECOND{}, I0{}, 1);
+  step(PC_FIRST{}, I0{}, 0, I0{});
+  step(PC_SECOND{}, I0{}, 1, I0{});
 
   // ---- tiles 1 .. nt-1, unrolled over the ring (tile j sits in slot j % 3: every LDS address of the loop is a constant).
   // Barrier B_j opens step 2j: every wave has finished step 2j-1, so tile j-1 is dead (its fragments are in registers) = the ring
   // slot tile j+2 goes to; the wait leaves only the four youngest pieces (tile j+1) in flight.
   auto tile_at = [&](auto slot_c, int j) __attribute__((always_inline)) {
     constexpr int SL = decltype(slot_c)::value;
-    if (j + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (j + 2 < nt) dma_tile(std::integral_constant<int, (SL + 2) % 3>{});
-    __builtin_amdgcn_sched_barrier(0);
-    step(PC_FULL{}, slot_c, 0);
-    step(PC_FULL{}, slot_c, 1);
+    tile_j = j;
+    if constexpr (STAGED) {
+      // (LDS operations of a wave complete in order and every step waits for its fragment reads: the ds_writes of the previous
+      // tile's G1 are long done; the wait states that in the code)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (!(WM_V4_DIAG & 1)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      step(PC_FULL{}, slot_c, 0, std::integral_constant<int, (WM_V4_DIAG & 4) ? 0 : 1>{});
+    } else {
+      if constexpr (!(WM_V4_DIAG & 8)) {
+        if (j + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if constexpr (!(WM_V4_DIAG & 1)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(WM_V4_DIAG & 4)) {
+        if (j + 2 < nt) {
+          dma_advance();
+          if constexpr ((WM_V4_DIAG & 16) != 0) { if (wave == 0) dma_tile(std::integral_constant<int, (SL + 2) % 3>{}); }   // one wave's pieces only
+          else dma_tile(std::integral_constant<int, (SL + 2) % 3>{});
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      step(PC_FULL{}, slot_c, 0, I0{});
+    }
+    step(PC_FULL{}, slot_c, 1, I0{});
   };
   int j = 1;
   for (; j + 2 < nt; j += 3) { tile_at(I1{}, j); tile_at(I2{}, j + 1); tile_at(I0{}, j + 2); }
@@ -491,8 +579,8 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
     if (j + 1 < nt) tile_at(I2{}, j + 1);
   }
   // ---- drain: step 2nt (softmax + PV of the last step), step 2nt+1 (its q-block 3)
-  step(PC_DRAIN1{}, I0{}, 0);
-  step(PC_DRAIN2{}, I0{}, 0);
+  step(PC_DRAIN1{}, I0{}, 0, I0{});
+  step(PC_DRAIN2{}, I0{}, 0, I0{});
   // MFMA result -> the epilogue's reads of O: the fence names the accumulators, so no read can be scheduled above it
   asm volatile("s_nop 15\n\ts_nop 15" : "+a"(ot[0][0]), "+a"(ot[0][1]), "+a"(ot[1][0]), "+a"(ot[1][1]), "+a"(ot[2][0]), "+a"(ot[2][1]), "+a"(ot[3][0]), "+a"(ot[3][1]));
 
