@@ -23,16 +23,17 @@ views = [int(x) for x in args] or [8, 32]
 H = 16
 for nv in views:
     M = nv * 1376
+    Ls = 1376 if os.environ.get("FRAMES") == "1" else M   # FRAMES=1: nv per-frame sequences of 1376 rows (21.5 key tiles) instead of one of nv * 1376
     g = torch.Generator(device="cpu").manual_seed(1)
     q = (torch.randn(H, M, 64, generator=g) * 0.125 * 1.4427 * 1.5).to(tdt).to(dev)
     k = (torch.randn(1, H, M, 64, generator=g) * 1.5).to(tdt).to(dev)
     v = torch.randn(1, H, M, 64, generator=g).to(tdt).to(dev)
     o = torch.empty(M, H * 64, device=dev, dtype=torch.int16)
     po = torch.empty(8, M, H * 64, device=dev); pml = torch.empty(8, H, M, 2, device=dev)
-    flags = torch.zeros((int(L.wm_op_attention_flag_count(M, M, H)),), device=dev, dtype=torch.int32)
-    fl = 4.0 * M * M * 64 * H
+    flags = torch.zeros((int(L.wm_op_attention_flag_count(M, Ls, H)),), device=dev, dtype=torch.int32)
+    fl = 4.0 * M * Ls * 64 * H
     def run():
-        assert L.wm_op_attention_ex(dt, p(q), p(k), p(v), p(o), H, M, M, 1, 0, 0, p(po), p(pml), p(flags), s) == 0
+        assert L.wm_op_attention_ex(dt, p(q), p(k), p(v), p(o), H, M, Ls, 1, 0, 0, p(po), p(pml), p(flags), s) == 0
     for qb, fn, rows, mf_tile in ((7, "wm_debug_attn3_stamps", 256, 32), (8, "wm_debug_attn_stamps", 512, 64)):
         if (qb == 7 and dt != 0) or os.environ.get("STAMP_QB", str(qb)) != str(qb):
             continue
@@ -44,18 +45,22 @@ for nv in views:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); run(); e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
-        units = ((M + rows - 1) // rows) * H
+        units = ((Ls + rows - 1) // rows) * (M // Ls) * H
         nb = min(units, 8192)
         buf = (C.c_ulonglong * (nb * 4))()
         assert getattr(L, fn)(buf, nb) == 0
         a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 4).astype(np.float64)
-        whole = a[a[:, 2] == (M // 64)]          # blocks that walked every key tile
+        whole = a[a[:, 2] == ((Ls + 63) // 64)]          # blocks that walked every key tile
         cyc, rt, nt = whole[:, 0], whole[:, 1], whole[:, 2]
         clk = cyc / rt * 100.0                   # MHz
         cpm = cyc / (nt * mf_tile)
-        print(json.dumps({"views": nv, "dtype": dt_name, "attn_qb": qb, "whole_blocks": int(len(whole)), "launch_us_stamp_build": round(ms * 1e3, 1),
+        print(json.dumps({"views": nv, "seq_len": Ls, "dtype": dt_name, "attn_qb": qb, "whole_blocks": int(len(whole)), "launch_us_stamp_build": round(ms * 1e3, 1),
                           "tflops_stamp_build": round(fl / ms / 1e9), "in_kernel_clock_mhz_median": round(float(np.median(clk)), 1),
                           "in_kernel_clock_mhz_p10_p90": [round(float(np.percentile(clk, 10)), 1), round(float(np.percentile(clk, 90)), 1)],
                           "cycles_per_mfma_median": round(float(np.median(cpm)), 2), "cycles_per_mfma_p10_p90": [round(float(np.percentile(cpm, 10)), 2), round(float(np.percentile(cpm, 90)), 2)],
-                          "loop_us_median": round(float(np.median(rt)) / 100.0, 1)}), flush=True)
+                          "loop_us_median": round(float(np.median(rt)) / 100.0, 1),
+                          # the launch as the blocks saw it (100 MHz realtime counter): first loop start -> last loop end, and the loop starts' spread
+                          "blocks": int(nb), "tiles_walked_counts": {str(int(k)): int((a[:, 2] == k).sum()) for k in np.unique(a[:, 2])},
+                          "span_us_first_start_to_last_end": round(float((a[:, 3] + a[:, 1]).max() - a[:, 3].min()) / 100.0, 1),
+                          "loop_start_us_p50_p90_max": [round(float(np.percentile(a[:, 3] - a[:, 3].min(), q)) / 100.0, 1) for q in (50, 90, 100)]}), flush=True)
     L.wm_set_tuning(b"attn_qb", -1)

@@ -24,8 +24,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define XOR_SINK 0
 #endif
 #define SM_HEAD "v_exp_f32 %[e0], %[s0]\n\tv_exp_f32 %[e1], %[s1]\n\t"
-#define SM_OUT [l0] "+v"(l0), [l1] "+v"(l1), [p] "=v"(p), [e0] "+v"(e0), [e1] "+v"(e1)
-#define SM_IN [s0] "v"(s0), [s1] "v"(s1)
+#define SM_OUT [l0] "+v"(l0), [l1] "+v"(l1), [p] "=&v"(p), [e0] "+v"(e0), [e1] "+v"(e1)
+#define SM_IN [s0] "v"(s0), [s1] "v"(s1), [ones] "v"(0x3f803f80u)
 
 #define EXP0 "v_exp_f32 %[e0], %[s0]\n\t"
 #define EXP1 "v_exp_f32 %[e1], %[s1]\n\t"
@@ -52,6 +52,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define GAP32(M) EXP0 EXP1 M "\n\tv_mov_b32 %[l0], %[s0]\n\tv_mov_b32 %[l1], %[s1]\n\tv_mov_b32 %[p], %[s0]"
 #elif ORDER == 10  // pricing: no transcendental at all
 #define GAP32(M) "v_mov_b32 %[e0], %[s0]\n\tv_mov_b32 %[e1], %[s1]\n\t" M "\n\t" ADD0 ADD1 PACK
+#elif ORDER == 12  // candidate: the row sum from the PACKED words (one v_dot2c with a pair of ones instead of two adds)
+#define GAP32(M) EXP0 EXP1 M "\n\t" PACK "\n\tv_dot2c_f32_bf16 %[l0], %[p], %[ones]"
+#elif ORDER == 13  // the same, the dot one gap late is not expressible here; dot before the MFMA's successor: exp exp pack MFMA dot
+#define GAP32(M) EXP0 EXP1 PACK "\n\t" M "\n\tv_dot2c_f32_bf16 %[l0], %[p], %[ones]"
 #elif ORDER == 11  // pricing: MFMA + five moves (no dependency between any two instructions of the gap)
 #define GAP32(M) "v_mov_b32 %[e0], %[s0]\n\tv_mov_b32 %[e1], %[s1]\n\t" M "\n\tv_mov_b32 %[l0], %[s0]\n\tv_mov_b32 %[l1], %[s1]\n\tv_mov_b32 %[p], %[s0]"
 #endif
