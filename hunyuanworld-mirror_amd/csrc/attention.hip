@@ -745,8 +745,10 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, int fast = 0) {   // fa
     if (e != hipSuccess) return e;
     a.only_if = a.unit_flags;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, LZ, STG>), grid, block, 0, s, a);
-  if (a.kv_splits > 1 && !a.force_partial)
+  // (timing-only switch for tools/attn_launch_cost.py: 1 skips the recompute pass behind a fast kernel, 2 the combine pass, 3 both — wrong results)
+  static const int dbg_skip = [] { const char* e = getenv("WM_ATTN_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
+  if (!(use_v3 && (dbg_skip & 1))) hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, LZ, STG>), grid, block, 0, s, a);
+  if (a.kv_splits > 1 && !a.force_partial && !(dbg_skip & 2))
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((units - nfull) * (QT / 16))), dim3(256), 0, s, a, QT);
   return hipGetLastError();
 }

@@ -173,6 +173,7 @@ __device__ __attribute__((aligned(128))) const uint4 wm_zero_rows_v4[72] = {};
 // diagnostic build only: per block {s_memtime, s_memrealtime} before and after the tile loop (wave 0), read back by
 // wm_debug_attn_stamps; no output depends on them
 __device__ unsigned long long wm_attn_stamp_buf[4 * 8192];
+__device__ unsigned long long wm_attn_stamp_buf2[2 * 8192];   // {s_memrealtime at the kernel's first instruction, after wave 0's last store}
 #endif
 
 // f16: P = 2^(S - m) is in f16's normal range for m - 14 <= S < m + 16.  m = ceil(first tile's row max) + 4 puts that window at
@@ -190,6 +191,9 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   __shared__ __attribute__((aligned(16))) char smem[(KRING + VRING) * TILE_B];  // K ring | V ring
   constexpr int VBASE = KRING * TILE_B;
 
+#ifdef WM_ATTN_STAMPS
+  const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, ql = lane & 31;
   const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
@@ -666,6 +670,12 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
         if (ok) *(uint4*)(op + 32 * d + 8 * g + 8 * h) = make_uint4(a0, a1, b0, b1);
       }
   }
+#ifdef WM_ATTN_STAMPS
+  if (tid == 0 && blockIdx.x < 8192) {   // (the partial-writing blocks return above: their exit stamp stays 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wm_attn_stamp_buf2[2 * blockIdx.x] = stamp_entry; wm_attn_stamp_buf2[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 }  // namespace
@@ -683,5 +693,14 @@ hipError_t wm_launch_attention_v4(const WmAttnArgs& a, int grid, int* flags, hip
 extern "C" int wm_debug_attn_stamps(unsigned long long* host_out, int nblocks) {
   if (nblocks > 8192) nblocks = 8192;
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wm_attn_stamp_buf), (size_t)nblocks * 4 * sizeof(unsigned long long));
+}
+extern "C" int wm_debug_attn_stamps_clear() {   // before the launch whose stamps are read: entries of blocks it does not have stay 0
+  void* p0 = nullptr; void* p1 = nullptr;
+  if (hipGetSymbolAddress(&p0, HIP_SYMBOL(wm_attn_stamp_buf)) != hipSuccess || hipGetSymbolAddress(&p1, HIP_SYMBOL(wm_attn_stamp_buf2)) != hipSuccess) return 1;
+  return (int)hipMemset(p0, 0, sizeof(unsigned long long) * 4 * 8192) | (int)hipMemset(p1, 0, sizeof(unsigned long long) * 2 * 8192);
+}
+extern "C" int wm_debug_attn_stamps2(unsigned long long* host_out, int nblocks) {
+  if (nblocks > 8192) nblocks = 8192;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wm_attn_stamp_buf2), (size_t)nblocks * 2 * sizeof(unsigned long long));
 }
 #endif

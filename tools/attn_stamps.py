@@ -43,24 +43,38 @@ for nv in views:
             for _ in range(8): run()
             torch.cuda.synchronize(); n += 8
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if qb == 8 and hasattr(L, "wm_debug_attn_stamps_clear"): assert L.wm_debug_attn_stamps_clear() == 0
         e0.record(); run(); e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         units = ((Ls + rows - 1) // rows) * (M // Ls) * H
-        nb = min(units, 8192)
+        nb = 8192 if (qb == 8 and hasattr(L, "wm_debug_attn_stamps_clear")) else min(units, 8192)   # (cleared buffer: every block of the launch, splits included)
         buf = (C.c_ulonglong * (nb * 4))()
         assert getattr(L, fn)(buf, nb) == 0
         a = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 4).astype(np.float64)
+        live = a[:, 2] > 0
+        a = a[live]
         whole = a[a[:, 2] == ((Ls + 63) // 64)]          # blocks that walked every key tile
         cyc, rt, nt = whole[:, 0], whole[:, 1], whole[:, 2]
         clk = cyc / rt * 100.0                   # MHz
         cpm = cyc / (nt * mf_tile)
-        print(json.dumps({"views": nv, "seq_len": Ls, "dtype": dt_name, "attn_qb": qb, "whole_blocks": int(len(whole)), "launch_us_stamp_build": round(ms * 1e3, 1),
+        extra = {}
+        if qb == 8 and hasattr(L, "wm_debug_attn_stamps2"):   # kernel entry / exit of the blocks that write O themselves
+            b2 = (C.c_ulonglong * (nb * 2))()
+            assert L.wm_debug_attn_stamps2(b2, nb) == 0
+            e = np.frombuffer(b2, dtype=np.uint64).reshape(nb, 2).astype(np.float64)[live]
+            fin = e[:, 1] > 0
+            t0 = e[fin, 0].min()
+            extra = {"entry_to_loop_start_us_median": round(float(np.median(a[fin, 3] - e[fin, 0])) / 100.0, 2),
+                     "loop_end_to_exit_us_median": round(float(np.median(e[fin, 1] - (a[fin, 3] + a[fin, 1]))) / 100.0, 2),
+                     "first_entry_to_last_exit_us": round(float(e[fin, 1].max() - t0) / 100.0, 1),
+                     "entry_us_p50_p90_max": [round(float(np.percentile(e[fin, 0] - t0, q)) / 100.0, 1) for q in (50, 90, 100)]}
+        print(json.dumps({**extra, "views": nv, "seq_len": Ls, "dtype": dt_name, "attn_qb": qb, "whole_blocks": int(len(whole)), "launch_us_stamp_build": round(ms * 1e3, 1),
                           "tflops_stamp_build": round(fl / ms / 1e9), "in_kernel_clock_mhz_median": round(float(np.median(clk)), 1),
                           "in_kernel_clock_mhz_p10_p90": [round(float(np.percentile(clk, 10)), 1), round(float(np.percentile(clk, 90)), 1)],
                           "cycles_per_mfma_median": round(float(np.median(cpm)), 2), "cycles_per_mfma_p10_p90": [round(float(np.percentile(cpm, 10)), 2), round(float(np.percentile(cpm, 90)), 2)],
                           "loop_us_median": round(float(np.median(rt)) / 100.0, 1),
                           # the launch as the blocks saw it (100 MHz realtime counter): first loop start -> last loop end, and the loop starts' spread
-                          "blocks": int(nb), "tiles_walked_counts": {str(int(k)): int((a[:, 2] == k).sum()) for k in np.unique(a[:, 2])},
+                          "blocks": int(len(a)), "tiles_walked_counts": {str(int(k)): int((a[:, 2] == k).sum()) for k in np.unique(a[:, 2])},
                           "span_us_first_start_to_last_end": round(float((a[:, 3] + a[:, 1]).max() - a[:, 3].min()) / 100.0, 1),
                           "loop_start_us_p50_p90_max": [round(float(np.percentile(a[:, 3] - a[:, 3].min(), q)) / 100.0, 1) for q in (50, 90, 100)]}), flush=True)
     L.wm_set_tuning(b"attn_qb", -1)
