@@ -28,7 +28,7 @@ if __name__ == "__main__":
     for r in tr:
         k = (name_of(r["Kernel_Name"]), int(r["Grid_Size_X"]))
         D[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); D[k][1] += 1
-    nfwd = sum(1 for r in tr if "im2col_kernel" in r["Kernel_Name"]) or 1
+    nfwd = sum(1 for r in tr if ("im2col_kernel" in r["Kernel_Name"] or "im2col_rows_kernel" in r["Kernel_Name"])) or 1
     rows = []
     for k, c in A.items():
         if k not in D or "SQ_VALU_MFMA_BUSY_CYCLES" not in c: continue
