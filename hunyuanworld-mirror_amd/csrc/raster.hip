@@ -9,9 +9,12 @@
 //   offsets    first pair of every (camera, tile)                      (_torch_impl.py:477-503)
 //   composite  front-to-back alpha blending per 16 x 16 tile, colour + depth channel, expected-depth normalisation
 //              (csrc/RasterizeToPixels3DGSFwd.cu:118-184, rendering.py:984-992)
-// All of it is HBM / VALU-bound integer and fp32 work (no MFMA): the compositing loop is one v_exp_f32 + ~12 VALU per
-// (pixel, Gaussian); a workgroup = one tile = 256 pixels = 4 waves, Gaussians staged 256 at a time through LDS and read
-// back as wave-uniform broadcasts; the tile loop stops when every pixel of the tile is saturated.
+// All of it is HBM / VALU-bound integer and fp32 work (no MFMA).  Compositing is written for 64-wide waves: a wave owns an
+// 8 x 8-pixel quadrant of a tile and walks the tile's depth-sorted list by itself — the Gaussian of a step is wave-uniform,
+// so its 48-byte record (written once per (camera, Gaussian) by the projection) arrives through SCALAR loads and its fields
+// are SGPR operands of the per-pixel arithmetic: no LDS staging, no workgroup barrier, no shared early-out.  A step is
+// branch-free per lane (the reference's skip / stop / blend decisions are three lane masks); the two branches are wave-uniform:
+// skip the blend when no pixel of the quadrant is hit, leave the list when all 64 are saturated.
 #include "wm_common.h"
 #include "wm_kernels.h"
 
@@ -23,18 +26,22 @@ constexpr int TILE = 16;
 constexpr float SH_C0 = 0.28209479177387814f;
 constexpr float ALPHA_THRESHOLD = 1.0f / 255.0f;
 
-struct G2D {  // per (camera, Gaussian): 32 B
+struct __attribute__((aligned(16))) G2D {  // per (camera, Gaussian): 48 B = three 16-byte scalar loads of the compositing pass
   float mx, my;         // pixel-space mean
-  float ca, cb, cc;     // conic
+  float ca, cb;         // conic
+  float cc, opacity;
   float depth;
-  int rect;             // x0 | y0 << 8 | x1 << 16 | y1 << 24 in tiles (tile grids up to 255 x 255)
+  float r, g, b;        // colour (view-independent: degree-0 SH or given colours)
+  int rect;             // x0 | y0 << 8 | x1 << 16 | y1 << 24 in tiles (tile grids up to 255 x 255); the compositing pass reads words 0-9 only
   int pad;
 };
+static_assert(sizeof(G2D) == 48, "G2D is read as three dwordx4");
 
 __global__ __launch_bounds__(256) void raster_project_kernel(const float* __restrict__ means, const float* __restrict__ quats,
                                                              const float* __restrict__ scales, const float* __restrict__ viewmats,
                                                              const float* __restrict__ Ks, int N, int C, int width, int height,
-                                                             float near_plane, float far_plane, G2D* __restrict__ g2d,
+                                                             float near_plane, float far_plane, const float* __restrict__ opac,
+                                                             const float4* __restrict__ rgb, G2D* __restrict__ g2d,
                                                              unsigned long long* __restrict__ counts, int* __restrict__ radii_out) {
   const int g = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
   if (g >= N) return;
@@ -110,6 +117,8 @@ __global__ __launch_bounds__(256) void raster_project_kernel(const float* __rest
     cnt = (unsigned long long)((x1 - x0) * (y1 - y0));
   }
   o.rect = x0 | (y0 << 8) | (x1 << 16) | (y1 << 24);
+  const float4 col = rgb[g];
+  o.opacity = opac[g]; o.r = col.x; o.g = col.y; o.b = col.z;
   o.pad = 0;
   const size_t idx = (size_t)c * N + g;
   g2d[idx] = o;
@@ -160,56 +169,107 @@ __global__ __launch_bounds__(256) void raster_offsets_kernel(const unsigned long
   offs[t] = lo;
 }
 
-__global__ __launch_bounds__(256) void raster_composite_kernel(const G2D* __restrict__ g2d, const float* __restrict__ opac,
-                                                               const float4* __restrict__ rgb, const unsigned int* __restrict__ vals,
-                                                               const unsigned int* __restrict__ offs, int N, int tw, int th, int width,
-                                                               int height, float* __restrict__ out_rgb, float* __restrict__ out_depth,
-                                                               float* __restrict__ out_alpha) {
-  __shared__ float4 s_a[256];  // mx, my, conic a, conic b
-  __shared__ float4 s_b[256];  // conic c, opacity, depth, -
-  __shared__ float4 s_c[256];  // r, g, b, -
+// One wave per tile region: a lane owns PX x PY neighbouring pixels, the wave 8 PX x 8 PY of them — PX = PY = 2: the wave is the
+// whole 16 x 16 tile and every record is fetched once per tile; PX = PY = 1: four independent waves per tile, one per 8 x 8
+// quadrant (finer skip / stop granularity, four times the scalar traffic).  Blending rules of the reference's forward
+// (csrc/RasterizeToPixels3DGSFwd.cu:118-184): a Gaussian is skipped for a pixel when its exponent is negative or its alpha below
+// 1/255; alpha is capped at 0.999; a pixel whose transmittance would fall to 1e-4 stops BEFORE blending that Gaussian; expected
+// depth = sum(depth * weight) / alpha (rendering.py:984-992).
+template <int PX, int PY>
+__global__ __launch_bounds__(256 / (PX * PY)) void raster_composite_kernel(const G2D* __restrict__ g2d, const unsigned int* __restrict__ vals,
+                                                                         const unsigned int* __restrict__ offs, int tw, int th, int width,
+                                                                         int height, float* __restrict__ out_rgb, float* __restrict__ out_depth,
+                                                                         float* __restrict__ out_alpha) {
+  constexpr int NP = PX * PY;               // pixels per lane
   const int tile = blockIdx.x, cam = blockIdx.y;
   const int ty = tile / tw, tx = tile - ty * tw;
-  const int tid = threadIdx.x;
-  const int i = ty * TILE + (tid >> 4), j = tx * TILE + (tid & 15);
-  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  const bool inside = i < height && j < width;
-  bool done = !inside;
-  const unsigned int start = offs[cam * tw * th + tile], end = offs[cam * tw * th + tile + 1];
-  float T = 1.0f, r = 0.f, g = 0.f, b = 0.f, d = 0.f;
-  for (unsigned int base = start; base < end; base += 256) {
-    if (__syncthreads_count(done) >= 256) break;  // also the barrier that protects the previous batch's reads
-    const unsigned int idx = base + tid;
-    if (idx < end) {
-      const unsigned int v = vals[idx];
-      const G2D o = g2d[v];
-      const unsigned int gi = v - (unsigned int)cam * (unsigned int)N;
-      s_a[tid] = make_float4(o.mx, o.my, o.ca, o.cb);
-      s_b[tid] = make_float4(o.cc, opac[gi], o.depth, 0.f);
-      s_c[tid] = rgb[gi];
-    }
-    __syncthreads();
-    const int nb = (int)min(256u, end - base);
-    for (int t = 0; t < nb && !done; ++t) {
-      const float4 A = s_a[t], B = s_b[t];
-      const float dx = A.x - px, dy = A.y - py;
-      const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-      const float alpha = fminf(0.999f, B.y * __expf(-sigma));
-      if (sigma < 0.f || alpha < ALPHA_THRESHOLD) continue;
-      const float nT = T * (1.0f - alpha);
-      if (nT <= 1e-4f) { done = true; break; }
-      const float vis = alpha * T;
-      const float4 Cc = s_c[t];
-      r += Cc.x * vis; g += Cc.y * vis; b += Cc.z * vis; d += B.z * vis;
-      T = nT;
+  const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // part: which 8 PX x 8 PY region of the tile
+  constexpr int PARTS_X = TILE / (8 * PX);
+  const int i0 = ty * TILE + (part / PARTS_X) * 8 * PY + (lane >> 3) * PY, j0 = tx * TILE + (part % PARTS_X) * 8 * PX + (lane & 7) * PX;
+  float px[NP], py[NP], T[NP], r[NP], g[NP], b[NP], d[NP];
+  bool open[NP];                            // the pixel still takes contributions
+  bool any_open = false;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int i = i0 + q / PX, j = j0 + q % PX;
+    px[q] = (float)j + 0.5f; py[q] = (float)i + 0.5f;
+    open[q] = i < height && j < width;
+    any_open |= open[q];
+    T[q] = 1.0f; r[q] = g[q] = b[q] = d[q] = 0.f;
+  }
+  unsigned int k = offs[cam * tw * th + tile];
+  const unsigned int end = offs[cam * tw * th + tile + 1];
+  if (__builtin_amdgcn_ballot_w64(any_open) == 0ull) return;   // a region outside the image (wave-uniform)
+  if (k < end) {
+    // Two-deep scalar pipeline over two register sets: while step k is blended, the record of step k + 1 is in flight together with
+    // the list entry its set will need next (two steps ahead).  The requests are asm statements because the compiler sinks a plain
+    // load below the saturation exit, next to its use; a set is settled (s_waitcnt, tied to its registers) one step after its
+    // request and before any exit, so no register of the loop is ever read, copied or left behind while a load still owns it.
+    const unsigned int last = end - 1;
+    typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    struct Rec { u32x8 lo; u32x2 hi; unsigned int nxt; };   // words 0-7 and 8-9 of a G2D record; nxt: the list entry this set fetches next
+    auto request = [&](Rec& o, unsigned int v, unsigned int at) __attribute__((always_inline)) {
+      const G2D* rp = g2d + v;
+      const unsigned int* ep = vals + (at < last ? at : last);
+      asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x20\n\ts_load_dword %2, %4, 0x0"
+                   : "=&s"(o.lo), "=&s"(o.hi), "=&s"(o.nxt) : "s"(rp), "s"(ep));
+    };
+    auto settle = [&](Rec& o) __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.lo), "+s"(o.hi), "+s"(o.nxt)); };
+    // one step; false when every pixel of the wave is saturated
+    auto step = [&](const Rec& w) __attribute__((always_inline)) {
+      const float mx = __uint_as_float(w.lo[0]), my = __uint_as_float(w.lo[1]), ca = __uint_as_float(w.lo[2]), cb = __uint_as_float(w.lo[3]);
+      const float cc = __uint_as_float(w.lo[4]), op = __uint_as_float(w.lo[5]), depth = __uint_as_float(w.lo[6]);
+      const float cr = __uint_as_float(w.lo[7]), cg = __uint_as_float(w.hi[0]), cbl = __uint_as_float(w.hi[1]);
+      float alpha[NP];
+      bool hit[NP], any_hit = false;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const float dx = mx - px[q], dy = my - py[q];
+        const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+        alpha[q] = fminf(0.999f, op * __expf(-sigma));
+        hit[q] = open[q] && !(sigma < 0.f) && !(alpha[q] < ALPHA_THRESHOLD);
+        any_hit |= hit[q];
+      }
+      if (__builtin_amdgcn_ballot_w64(any_hit) == 0ull) return true;   // nobody in the region sees this Gaussian
+      bool still = false;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const float nT = T[q] * (1.0f - alpha[q]);
+        const bool stop = hit[q] && nT <= 1e-4f;
+        const bool blend = hit[q] && !stop;
+        const float vis = blend ? alpha[q] * T[q] : 0.f;
+        r[q] += cr * vis; g[q] += cg * vis; b[q] += cbl * vis; d[q] += depth * vis;
+        T[q] = blend ? nT : T[q];
+        open[q] = open[q] && !stop;
+        still |= open[q];
+      }
+      return __builtin_amdgcn_ballot_w64(still) != 0ull;
+    };
+    Rec A, B;
+    request(A, __builtin_amdgcn_readfirstlane(vals[k]), k + 2); settle(A);
+    request(B, __builtin_amdgcn_readfirstlane(vals[k + 1 < last ? k + 1 : last]), k + 3);
+    for (;;) {
+      bool alive = step(A);
+      settle(B);
+      if (!alive || ++k >= end) break;
+      request(A, A.nxt, k + 3);
+      alive = step(B);
+      settle(A);
+      if (!alive || ++k >= end) break;
+      request(B, B.nxt, k + 3);
     }
   }
-  if (inside) {
-    const size_t pix = ((size_t)cam * height + i) * width + j;
-    const float al = 1.0f - T;
-    out_rgb[3 * pix] = r; out_rgb[3 * pix + 1] = g; out_rgb[3 * pix + 2] = b;
-    out_depth[pix] = d / fmaxf(al, 1e-10f);  // expected depth (rendering.py:984-992)
-    out_alpha[pix] = al;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int i = i0 + q / PX, j = j0 + q % PX;
+    if (i < height && j < width) {
+      const size_t pix = ((size_t)cam * height + i) * width + j;
+      const float al = 1.0f - T[q];
+      out_rgb[3 * pix] = r[q]; out_rgb[3 * pix + 1] = g[q]; out_rgb[3 * pix + 2] = b[q];
+      out_depth[pix] = d[q] / fmaxf(al, 1e-10f);
+      out_alpha[pix] = al;
+    }
   }
 }
 
@@ -263,9 +323,9 @@ hipError_t wm_launch_rasterize(const WmRasterArgs& a, hipStream_t s, unsigned lo
   while ((1 << tile_bits) <= tiles) ++tile_bits;  // = bit_length(tiles), as the reference
   int cam_bits = 0;
   while ((1ull << cam_bits) < C) ++cam_bits;
-  hipLaunchKernelGGL(raster_project_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)C), dim3(256), 0, s, a.means, a.quats, a.scales, a.viewmats,
-                     a.Ks, a.N, a.C, a.width, a.height, 0.01f, 1e10f, w.g2d, w.counts, a.radii_out);
   hipLaunchKernelGGL(raster_color_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a.colors, a.N, a.is_sh, w.rgb);
+  hipLaunchKernelGGL(raster_project_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)C), dim3(256), 0, s, a.means, a.quats, a.scales, a.viewmats,
+                     a.Ks, a.N, a.C, a.width, a.height, 0.01f, 1e10f, a.opacities, w.rgb, w.g2d, w.counts, a.radii_out);
   hipError_t e = hipMemsetAsync(w.counts + CN, 0, 8, s);
   if (e != hipSuccess) return e;
   size_t tb = w.cub_bytes;
@@ -291,7 +351,19 @@ hipError_t wm_launch_rasterize(const WmRasterArgs& a, hipStream_t s, unsigned lo
   }
   hipLaunchKernelGGL(raster_offsets_kernel, dim3((unsigned)((C * tiles + 1 + 255) / 256)), dim3(256), 0, s, sorted_keys, (unsigned int)n_isects, a.C, tiles,
                      tile_bits, w.tile_offs);
-  hipLaunchKernelGGL(raster_composite_kernel, dim3((unsigned)tiles, (unsigned)C), dim3(256), 0, s, w.g2d, a.opacities, w.rgb, sorted_vals, w.tile_offs, a.N, tw,
-                     th, a.width, a.height, a.out_rgb, a.out_depth, a.out_alpha);
+  // pixels per lane of the compositing pass: a whole tile per wave when that still gives every SIMD several waves, half a tile
+  // otherwise (8 views at 518^2, 8 712 tiles: 4 / 2 / 1 pixels per lane 3.14 / 3.31 / 4.37 ms; 2 views, 2 178 tiles: end to end
+  // 0.87 / 0.74 / 0.79 ms; the LDS-staged workgroup-per-tile form it replaces: 3.70 ms, 0.83 ms — profiles/r03_raster_ab.md)
+  static const int ppl_env = [] { const char* e = getenv("WM_RASTER_PPL"); return e ? atoi(e) : 0; }();   // A/B: 1, 2, 4
+  const int ppl = ppl_env ? ppl_env : ((long)tiles * C >= 8192 ? 4 : 2);
+  if (ppl == 1)
+    hipLaunchKernelGGL((raster_composite_kernel<1, 1>), dim3((unsigned)tiles, (unsigned)C), dim3(256), 0, s, w.g2d, sorted_vals, w.tile_offs, tw, th, a.width,
+                       a.height, a.out_rgb, a.out_depth, a.out_alpha);
+  else if (ppl == 2)
+    hipLaunchKernelGGL((raster_composite_kernel<2, 1>), dim3((unsigned)tiles, (unsigned)C), dim3(128), 0, s, w.g2d, sorted_vals, w.tile_offs, tw, th, a.width,
+                       a.height, a.out_rgb, a.out_depth, a.out_alpha);
+  else
+    hipLaunchKernelGGL((raster_composite_kernel<2, 2>), dim3((unsigned)tiles, (unsigned)C), dim3(64), 0, s, w.g2d, sorted_vals, w.tile_offs, tw, th, a.width,
+                       a.height, a.out_rgb, a.out_depth, a.out_alpha);
   return hipGetLastError();
 }

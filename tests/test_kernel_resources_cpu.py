@@ -172,3 +172,45 @@ def test_conv3x3_kernels_do_not_spill(tmp_path):
         assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, name
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
     assert n >= 8
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_raster_compositing_streams_records_through_scalar_loads(tmp_path):
+    """The compositing pass (raster.hip) is written for 64-wide waves: the Gaussian of a step is wave-uniform, fetched by scalar loads
+    into two alternating SGPR sets whose requests are asm statements (the compiler sinks plain loads next to their use).  What that
+    needs from the ISA and nothing else would catch: the records really arrive by s_load (not per-lane loads + readfirstlane), there is
+    no LDS traffic and no barrier, a set is settled (s_waitcnt) between its request and its first use, and nothing copies a set's
+    registers while a load may still own them."""
+    flags = None
+    for line in open(os.path.join(CSRC, "Makefile")):
+        if line.startswith("CXXFLAGS"):
+            flags = [f.replace("$(ARCH)", "gfx950") for f in line.split("=", 1)[1].split() if not f.startswith("$(")]
+    asm = tmp_path / "raster.s"
+    r = subprocess.run(["hipcc", *flags, "-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, "raster.hip"), "-o", str(asm),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for b in re.split(r"remark: Function Name: ", r.stderr)[1:]:
+        if "raster_composite_kernel" in b.split()[0]:
+            get = lambda key: int(re.search(key + r": (\d+)", b).group(1))
+            assert get(r"ScratchSize \[bytes/lane\]") == 0 and get(r"VGPRs") <= 64 and get(r"Occupancy \[waves/SIMD\]") == 8, b[:300]
+    kernels = re.findall(r"^(_ZN\S*raster_composite_kernel\S*):[^\n]*\n(.*?)^\.Lfunc_end", open(asm).read(), flags=re.S | re.M)
+    assert len(kernels) == 3      # 1, 2 and 4 pixels per lane
+    for name, body in kernels:
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        assert not [l for l in lines if l.startswith("ds_") or l.startswith("s_barrier")], name
+        marks = [i for i, l in enumerate(body.split("\n")) if "Loop Header" in l or "in Loop: Header" in l]
+        loop = [l.strip() for l in body.split("\n")[min(marks):max(marks) + 400] if l.strip() and not l.strip().startswith(";")]
+        x8 = [i for i, l in enumerate(loop) if l.startswith("s_load_dwordx8")]
+        assert len(x8) >= 2, (name, "two register sets, each requested in the loop")
+        assert not [l for l in loop if l.startswith("global_load") or l.startswith("buffer_load") or l.startswith("flat_load")], name
+        for i in x8:   # from a request to the next s_waitcnt lgkmcnt(0): no instruction names a register of the requested tuple
+            lo, hi = [int(x) for x in re.search(r"s\[(\d+):(\d+)\]", loop[i]).groups()]
+            j = i + 1
+            while j < len(loop) and not loop[j].startswith("s_waitcnt lgkmcnt(0)"):
+                if not loop[j].startswith("s_load_"):
+                    regs = [int(x) for x in re.findall(r"\bs(\d+)\b", loop[j])]
+                    for a, b_ in re.findall(r"s\[(\d+):(\d+)\]", loop[j]):
+                        regs += list(range(int(a), int(b_) + 1))
+                    assert not [x for x in regs if lo <= x <= hi], (name, loop[i], loop[j])
+                j += 1
+            assert j < len(loop), (name, "no settle behind a request")
