@@ -1612,7 +1612,6 @@ extern "C" wm_status wm_op_conv3x3_up(int dtype, const float* x, const void* w16
   memset(&a, 0, sizeof(a));
   a.x = x; a.w = w16; a.bias = bias; a.y = y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.ksize = 3; a.stride = 1; a.pad = 1;
   a.Ho = Hi; a.Wo = Wi; a.dtype = dtype; a.up_hs = Hs; a.up_ws = Ws; a.up_addx = addx; a.up_addy = addy;
-  if (getenv("WM_DBG_LATE")) a.relu_out = 7;
   return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
 // ---------------------------------------------------------------- image ingest
