@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -377,7 +377,8 @@ hipError_t launch_cfg(const WmGemmArgs& a, hipStream_t s) {
 // the wave's SM x SN grid; operands were swapped (D = W_frag * A_frag), so lane (l15 = lane & 15, lq = lane >> 4) owns
 // row 16 i + l15 and the 4 consecutive columns 16 j + 4 lq .. + 3.
 template <int T, int EPI, int SM, int SN>
-__device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM][SN], int rowb, int colb, int lane) {
+__device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM][SN], int rowb, int colb, int lane, int mlim) {
+  // mlim: first row this wave must NOT write (p.M, or the end of the wave's share of a shortened row band)
   const int l15 = lane & 15, lq = lane >> 4;
   // ---------------- epilogue ----------------
   if constexpr (EPI == WM_EPI_QKV) {
@@ -404,7 +405,7 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
     }
     auto rope_rows = [&](int i, float4 (&cs)[2], float4 (&sn)[2]) {
       const int row = rowb + i * 16 + l15;
-      const int rr = row < p.M ? row : 0;
+      const int rr = row < mlim ? row : 0;
       const int t = rr - (int)(((float)rr + 0.5f) * q.inv_tpv) * q.tokens_per_view;  // see gemm_nt_kernel
       int py = 0, px = 0;
       if (t >= q.patch_start) {
@@ -419,8 +420,9 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
     if (do_rope) rope_rows(0, csn[0], snn[0]);
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
+      if (rowb + i * 16 >= mlim) break;  // wave-uniform: the rest of the wave's rows are past the band / matrix end
       const int row = rowb + i * 16 + l15;
-      const bool row_ok = row < p.M;
+      const bool row_ok = row < mlim;
       if (do_rope && i + 1 < SM) rope_rows(i + 1, csn[(i + 1) & 1], snn[(i + 1) & 1]);
       float v[4][4];  // [j: 16-col group][e]: column 16j + 4*lq + e of this head
 #pragma unroll
@@ -495,6 +497,7 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
       if ((p.N & 7) == 0 && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0) {
 #pragma unroll
         for (int i = 0; i < SM; ++i) {
+          if (rowb + i * 16 >= mlim) break;  // wave-uniform: the rest of the wave's rows are past the band / matrix end
           const int row = rowb + i * 16 + l15;
 #pragma unroll
           for (int jp = 0; jp < SN / 2; ++jp) {
@@ -510,7 +513,7 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
             swap16(u[0].x, u[1].x);
             swap16(u[0].y, u[1].y);
             const int col = colb + (2 * jp + (lq & 1)) * 16 + 4 * (lq & 2);  // 8 columns from here
-            if (row < p.M && col < p.N) *(uint4*)((u16*)p.C + (size_t)row * p.ldc + col) = make_uint4(u[0].x, u[0].y, u[1].x, u[1].y);
+            if (row < mlim && col < p.N) *(uint4*)((u16*)p.C + (size_t)row * p.ldc + col) = make_uint4(u[0].x, u[0].y, u[1].x, u[1].y);
           }
         }
         return;
@@ -524,19 +527,20 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
 #pragma unroll
         for (int j = 0; j < SN; ++j) {
           const int col = colb + j * 16 + 4 * lq;
-          o[j] = (row < p.M && col < p.N) ? *(const float4*)((const float*)p.C + (size_t)row * p.ldc + col) : make_float4(0, 0, 0, 0);
+          o[j] = (row < mlim && col < p.N) ? *(const float4*)((const float*)p.C + (size_t)row * p.ldc + col) : make_float4(0, 0, 0, 0);
         }
       };
       load_old(0, old[0]);
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
+        if (rowb + i * 16 >= mlim) break;  // wave-uniform: the rest of the wave's rows are past the band / matrix end
         if (i + 1 < SM) load_old(i + 1, old[(i + 1) & 1]);
         const int row = rowb + i * 16 + l15;
 #pragma unroll
         for (int j = 0; j < SN; ++j) {
           const int col = colb + j * 16 + 4 * lq;
           const float4 o = old[i & 1][j], gm = gm4[j], bs = bs4[j];
-          if (row < p.M && col < p.N) {
+          if (row < mlim && col < p.N) {
             const float4 nv = make_float4(o.x + gm.x * (acc[i][j][0] + bs.x), o.y + gm.y * (acc[i][j][1] + bs.y), o.z + gm.z * (acc[i][j][2] + bs.z), o.w + gm.w * (acc[i][j][3] + bs.w));
             *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = nv;
             if (p.C2) *(float4*)(p.C2 + (size_t)row * p.ldc2 + col) = nv;  // tap half (block-uniform branch)
@@ -547,8 +551,9 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
     }
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
+      if (rowb + i * 16 >= mlim) break;  // wave-uniform: the rest of the wave's rows are past the band / matrix end
       const int row = rowb + i * 16 + l15;
-      if (row >= p.M) continue;
+      if (row >= mlim) continue;
 #pragma unroll
       for (int j = 0; j < SN; ++j) {
         const int col = colb + j * 16 + 4 * lq;
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt16_kernel(const WmGemmArg
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
   }
-  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, p.M);
 }
 
 template <int T, int EPI, int WM, int WN, int TM, int TN, int NSTAGE>
@@ -775,8 +780,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const WmGemmArgs p) {
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
-  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wr * WROWS, n0 + wc * 64, lane);
+  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wr * WROWS, n0 + wc * 64, lane, p.M);
 }
+
+#ifdef WM_GEMM_STAMPS
+// diagnostic build only (make stamps): wave 0 of every block records, on the 100 MHz s_memrealtime counter, its entry, the start and
+// the end of its K loop and its exit (after its own stores have drained), the shader clock count of the loop and the CU it ran on;
+// read back by wm_debug_gemm_stamps (tools/gemm_timeline.py).  No output depends on the stamps.
+__device__ unsigned long long wm_gemm_stamp_buf[8 * 8192];
+#endif
 
 // Ping-pong v2 (256 x 256 only): same two-group structure, but the LDS-DMA runs TWO K-tiles ahead inside the same two
 // 64-KiB buffers.  Quadrant order (0,0) (0,1) (1,1) (1,0) with B(qn=0) kept in registers for the whole K-tile, so the
@@ -790,19 +802,61 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const WmGemmArgs p) {
 // QI = 3 (192-row tile: wave tile 96 x 64, quadrants of 3 sub-tiles): the A regions have 12 pieces, so waves 0-3 carry
 // two per region and waves 4-7 one; the counted waits then differ per wave half (R_A0B0 = nA + 2, R_B1 = 2, R_A1 = nA,
 // nA = 2 | 1  ->  12 / 10 / 12 / 8 / 4 / 2  |  9 / 7 / 9 / 6 / 3 / 1), selected by a wave-uniform branch.
-template <int T, int EPI, int PRIO, int DBG = 0, int QI = 4>
+//
+// VER = 3 (round 4) — HALF THE BARRIERS.  In-kernel stamps (profiles/r04_gemm_timeline.md) put a K-tile at 2 260 - 2 720 cycles
+// against 1 536 / 2 048 of MFMA issue, the same with every operand row an L2 hit, 8 % less with the LDS-DMA removed, and
+// barely less with MFMAs removed (a band cut from 12 to 10.75 units: -3 %): the eight s_barrier hand-offs of a K-tile
+// (~ 90 cycles each in which the matrix pipe has nothing queued) are what the loop is made of.  v3 keeps the schedule of v2
+// but lets group 0 ("X") put its barrier BEFORE its MFMA stage only and group 1 ("Y") BEFORE its load stage only:
+//      X:  L(0) | B  M(k)  L(k+1) | B  M(k+1)  L(k+2) | ...
+//      Y:       | B  L(k)  M(k)   | B  L(k+1)  M(k+1) | ...
+// so inside an interval X's MFMAs run beside Y's loads, Y's MFMAs queue right behind them (no barrier in between) beside
+// X's next loads, and only one hand-off per phase is left.  Ordering, with I_k the interval after barrier k = 4 t + p:
+//  WAR  a region is refilled two phases after the phase whose load stage read it, instead of one: {A0,B0}(t+2) in L(t,2),
+//       B1(t+2) in L(t,3), A1(t+2) in L(t+1,0).  Its readers were X's L(t,p) in I_(k-1) and Y's L(t,p) in I_k; the first
+//       refill is X's in I_(k+1), behind barrier k+1, and Y retired its reads (lgkmcnt(0)) before its M(t,p).
+//  RAW  a region of K-tile t+1 is first read by X in the interval before Y reads it; every wave waits for its own pieces of
+//       it before the barrier that opens that interval: X at the end of the load stage in front of that barrier, Y after
+//       the MFMA stage in front of it.  Pieces are issued in the order A0B0(k) B1(k) A1(k), k = 0, 1, ... by every wave
+//       (c0 = nA + 2, c1 = 2, c2 = nA pieces, c = 2 nA + 4; nA = 2, or 1 for waves 4-7 of the 192-row tile), so with
+//       n1 = [t+1 < nk], n2 = [t+2 < nk] the counted waits are
+//         X  end of L(t,0): B1(t)       c2 + n1 c              end of L(t,1): A1(t)   n1 c
+//            end of L(t,3): A0B0(t+1)   c1 + c2 + n2 (c0 + c1)
+//         Y  end of M(t,0): A1(t)       n1 c                   end of M(t,2): A0B0(t+1)   c1 + c2 + n2 c0
+//            end of M(t,3): B1(t+1)     c2 + n2 (c0 + c1)
+//       and everybody waits for A0B0(0) and B1(0) (c2 + [nk > 1] c younger) before one common barrier in front of the loop.
+template <int T, int EPI, int PRIO, int DBG = 0, int QI = 4, int VER = 2>
 __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   constexpr int SM = 2 * QI, SN = 4, WROWS = SM * 16, BM = 2 * WROWS, BN = 256;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int APC = QI * 2;  // 8-row pieces per (wave row half, quadrant): 8 or 6
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef WM_GEMM_STAMPS
+  const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int ntn = (p.N + BN - 1) / BN, ntm = p.sched_bands > 0 ? p.sched_bands : (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, ntm * ntn);
   int band, nt;
   tile_of(lid, ntm, ntn, p.group_bands, band, nt);
-  const int m0 = band * BM, n0 = nt * BN;
+  // Row band of this block, in 16-row units.  With a schedule (wm_launch_gemm) the M rows are cut into `ntm` bands of
+  // floor / ceil(units / ntm) units, spread evenly (band b starts at floor(b units / ntm)), so that ntm x ntn fills whole
+  // rounds of the CUs instead of leaving the last round a third empty (M = 11008: 696 tiles of 192 rows = 2.72 rounds ->
+  // 768 tiles of 160 / 176 rows = 3.0).  A band of S units is S0 = ceil(S / 2) units for wave group 0 and S1 = S - S0 for
+  // group 1; the LDS image keeps the full-tile layout (group 1's rows start at WROWS), only the SOURCE rows of group 1 move
+  // up to follow group 0's, the MFMAs of the units a group does not have are skipped, and the epilogue stops at the band's end.
+  int u0, S;
+  if (p.sched_bands > 0) {
+    u0 = (int)((long long)band * p.sched_units / ntm);
+    S = (int)((long long)(band + 1) * p.sched_units / ntm) - u0;
+  } else {
+    u0 = band * 2 * SM;
+    S = 2 * SM;
+  }
+  const int S0 = (S + 1) >> 1, Sw = wr ? S - S0 : S0;        // units of this wave's group (block- / wave-uniform)
+  const int nB = Sw - QI;                                    // units in the group's second quadrant row: QI, QI - 1 or QI - 2
+  const int m0 = u0 * 16, n0 = nt * BN;
   const int l15 = lane & 15, lq = lane >> 4;
   const bool two = QI == 4 || wave < 4;  // this wave carries two A pieces per region (wave-uniform)
 
@@ -823,13 +877,14 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
     }
     const int r = pl * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    int gr = (DBG == 4 ? 0 : (isA ? m0 : n0)) + r;
+    int gr = (DBG == 4 ? 0 : (isA ? m0 : n0)) + (isA && r >= WROWS ? r - WROWS + 16 * S0 : r);
     const int lim = (isA ? p.M : p.N) - 1;
     gr = gr < lim ? gr : lim;
     gp[i] = (isA ? (const u16*)p.A + (size_t)gr * p.lda : (const u16*)p.W + (size_t)gr * p.ldw) + c * 8;
     loff[i] = (isA ? 0 : A_BYTES) + pl * 1024;
   }
-  auto dma = [&](int buf, int i0, int i1) {
+  auto dma = [&](int buf, int i0, int i1, bool in_loop = false) {
+    if ((DBG == 6 || (DBG >= 16 && (DBG & 1))) && in_loop) return;  // timing experiment: no LDS-DMA inside the K loop (the counted waits then never block)
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
       if ((i == 1 || i == 7) && !two) continue;  // wave-uniform
@@ -854,27 +909,134 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
 
   const int nk = p.K / 64;
   dma(0, 0, 8);
-  if (nk > 1) { dma(1, 0, 8); WM_W2(12, 9); } else WM_W2(4, 3);
+  if (nk > 1) dma(1, 0, 8);
+  if constexpr (VER == 3) {   // A0B0(0) and B1(0): group X reads B1(0) in the first interval, before group Y has had a wait of its own
+    if (nk > 1) WM_W2(10, 7); else WM_W2(2, 1);
+  } else {
+    if (nk > 1) WM_W2(12, 9); else WM_W2(4, 3);
+  }
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
+  if (VER == 2 && wr == 1) __builtin_amdgcn_s_barrier();
 
+#ifdef WM_GEMM_STAMPS
+  const unsigned long long st_loop0 = __builtin_amdgcn_s_memrealtime(), st_cyc0 = __builtin_amdgcn_s_memtime();
+#endif
+  if constexpr (VER == 3) {
+    constexpr int NAY = QI == 4 ? 2 : 1;                      // A pieces per region of a group-1 wave (group 0 always carries 2)
+    constexpr int CY = 2 * NAY + 4, C0Y = NAY + 2;
+    auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto bar = [&]() { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+    auto mfma_on = [&]() { __builtin_amdgcn_sched_barrier(0); if (PRIO) __builtin_amdgcn_s_setprio(1); };
+    auto mfma_off = [&]() { if (PRIO) __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); };
+    auto kloop3 = [&](auto nbc) __attribute__((always_inline)) {
+      constexpr int NB = decltype(nbc)::value;
+      // (Tried and dropped: reading only the k-half 0 fragments in the load stage and the k-half 1 fragments behind the k-half 0
+      // MFMAs of the MFMA stage itself — the wait in the middle of the stage cost more than the shorter load stages gave: fc1
+      // 101 -> 105 us, profiles/r04_gemm_timeline.md.)
+      auto rd_a = [&](int t, int q0, int n) {   // A fragments of quadrant row q0 (first unit index), both k-halves
+        const char* tile = smem + (t & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          a[i][0] = *(const s16x8*)(tile + a_base + (q0 + i) * 2048 + foff0);
+          a[i][1] = *(const s16x8*)(tile + a_base + (q0 + i) * 2048 + foff1);
+        }
+      };
+      auto rd_b = [&](int t, int j0, s16x8 (&b)[2][2]) {
+        const char* tile = smem + (t & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          b[j][0] = *(const s16x8*)(tile + b_base + (j0 + j) * 2048 + foff0);
+          b[j][1] = *(const s16x8*)(tile + b_base + (j0 + j) * 2048 + foff1);
+        }
+      };
+      auto L0 = [&](int t) {
+        rd_b(t, 0, b0); rd_a(t, 0, QI);
+        if (t >= 1 && t + 1 < nk) dma((t + 1) & 1, 6, 8, true);   // A1(t+1): its last readers were the L(t-1,2)
+      };
+      auto L1 = [&](int t) { rd_b(t, 2, b1); };
+      auto L2 = [&](int t) {
+        rd_a(t, QI, NB);
+        if (t + 2 < nk) dma(t & 1, 0, 4, true);                   // {A0,B0}(t+2): last readers the L(t,0)
+      };
+      auto L3 = [&](int t) {
+        if (t + 2 < nk) dma(t & 1, 4, 6, true);                   // B1(t+2): last readers the L(t,1)
+      };
+      auto mm = [&](int r0, int n, int c0, s16x8 (&b)[2][2]) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int i = 0; i < n; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[r0 + i][c0 + j] = mfma16<T>(b[j][kh], a[i][kh], acc[r0 + i][c0 + j]);
+      };
+      auto M0 = [&](int) { mfma_on(); mm(0, QI, 0, b0); mfma_off(); };
+      auto M1 = [&](int) { mfma_on(); mm(0, QI, 2, b1); mfma_off(); };
+      auto M2 = [&](int) { mfma_on(); mm(QI, NB, 2, b1); mfma_off(); };
+      auto M3 = [&](int) { mfma_on(); mm(QI, NB, 0, b0); mfma_off(); };
+      if (wr == 0) {
+        // ---- group X (nA = 2: c0 4, c1 2, c2 2, c 8): load stage one phase ahead of its barrier
+        L0(0);
+        if (nk > 1) wait_vmcnt<10>(); else wait_vmcnt<2>();
+        for (int t = 0; t < nk; ++t) {
+          const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+          lgk0(); bar(); M0(t);
+          L1(t);
+          if (n1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+          lgk0(); bar(); M1(t);
+          L2(t);
+          lgk0(); bar(); M2(t);
+          L3(t);
+          if (n1) { if (n2) wait_vmcnt<10>(); else wait_vmcnt<4>(); }
+          bar(); M3(t);
+          if (n1) {
+            L0(t + 1);
+            if (n2) wait_vmcnt<10>(); else wait_vmcnt<2>();
+          }
+        }
+      } else {
+        // ---- group Y (nA = NAY): barrier, load stage, MFMA stage; its waits sit behind the MFMA stages
+        for (int t = 0; t < nk; ++t) {
+          const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+          bar(); L0(t); lgk0(); M0(t);
+          if (n1) wait_vmcnt<CY>(); else wait_vmcnt<0>();
+          bar(); L1(t); lgk0(); M1(t);
+          bar(); L2(t); lgk0(); M2(t);
+          if (n1) { if (n2) wait_vmcnt<2 + NAY + C0Y>(); else wait_vmcnt<2 + NAY>(); }
+          bar(); L3(t); M3(t);
+          if (n1) { if (n2) wait_vmcnt<NAY + C0Y + 2>(); else wait_vmcnt<NAY>(); }
+        }
+      }
+    };
+    if (nB == QI) kloop3(std::integral_constant<int, QI>{});
+    else if (nB == QI - 1) kloop3(std::integral_constant<int, QI - 1>{});
+    else kloop3(std::integral_constant<int, QI - 2>{});
+  } else {
+  // timing experiments (stamps build, DBG = 16 + mask; results are wrong): 1 no LDS-DMA in the loop, 2 no fragment reads after the
+  // first K-tile, 4 no barriers in the loop, 8 no s_setprio
+  constexpr bool NO_RD = DBG >= 16 && (DBG & 2), NO_BAR = DBG >= 16 && (DBG & 4), NO_PRIO = DBG >= 16 && (DBG & 8);
   auto stage_end = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!NO_BAR) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (PRIO) __builtin_amdgcn_s_setprio(1);
+    if (PRIO && !NO_PRIO) __builtin_amdgcn_s_setprio(1);
   };
   auto mfma_end = [&]() {
-    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    if (PRIO && !NO_PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!NO_BAR) __builtin_amdgcn_s_barrier();
   };
 
+  // The K loop, instantiated per number NB of 16-row units in this wave group's SECOND quadrant row (a shortened band drops
+  // units from the end of the group): the choice is made once, outside the loop (a guard per MFMA group inside it measured
+  // +30 % on the loop).  The first quadrant row is always whole (wm_launch_gemm keeps bands >= 4 QI - 4 units).
+  auto kloop = [&](auto nbc) __attribute__((always_inline)) {
+  constexpr int NB = decltype(nbc)::value;
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
     const char* tile = smem + buf * STAGE;
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
     // ---- phase 0: quadrant (0,0)
+    if (!NO_RD || t == 0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       b0[j][0] = *(const s16x8*)(tile + b_base + j * 2048 + foff0);
@@ -884,6 +1046,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
     for (int i = 0; i < QI; ++i) {
       a[i][0] = *(const s16x8*)(tile + a_base + i * 2048 + foff0);
       a[i][1] = *(const s16x8*)(tile + a_base + i * 2048 + foff1);
+    }
     }
     if (n1) WM_W2(10, 7); else WM_W2(2, 1);
     stage_end();
@@ -895,12 +1058,14 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<T>(b0[j][kh], a[i][kh], acc[i][j]);
     mfma_end();
     // ---- phase 1: quadrant (0,1); refill {A0,B0} with K-tile t+2
+    if (!NO_RD || t == 0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       b1[j][0] = *(const s16x8*)(tile + b_base + (2 + j) * 2048 + foff0);
       b1[j][1] = *(const s16x8*)(tile + b_base + (2 + j) * 2048 + foff1);
     }
-    if (n2) { dma(buf, 0, 4); WM_W2(12, 9); } else if (n1) WM_W2(8, 6); else wait_vmcnt<0>();
+    }
+    if (n2) { dma(buf, 0, 4, true); WM_W2(12, 9); } else if (n1) WM_W2(8, 6); else wait_vmcnt<0>();
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -910,48 +1075,73 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
         for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16<T>(b1[j][kh], a[i][kh], acc[i][2 + j]);
     mfma_end();
     // ---- phase 2: quadrant (1,1); refill B1
+    if (!NO_RD) {
 #pragma unroll
-    for (int i = 0; i < QI; ++i) {
+    for (int i = 0; i < NB; ++i) {
       a[i][0] = *(const s16x8*)(tile + a_base + (QI + i) * 2048 + foff0);
       a[i][1] = *(const s16x8*)(tile + a_base + (QI + i) * 2048 + foff1);
     }
-    if (n2) dma(buf, 4, 6);
+    }
+    if (n2) dma(buf, 4, 6, true);
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < QI; ++i)
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[QI + i][2 + j] = mfma16<T>(b1[j][kh], a[i][kh], acc[QI + i][2 + j]);
     mfma_end();
     // ---- phase 3: quadrant (1,0) from registers; refill A1; next K-tile's {A0,B0} must have landed
-    if (n2) { dma(buf, 6, 8); WM_W2(12, 9); } else if (n1) WM_W2(4, 3);
+    if (n2) { dma(buf, 6, 8, true); WM_W2(12, 9); } else if (n1) WM_W2(4, 3);
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int i = 0; i < QI; ++i)
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[QI + i][j] = mfma16<T>(b0[j][kh], a[i][kh], acc[QI + i][j]);
     mfma_end();
   }
+  };
+  if (nB == QI) kloop(std::integral_constant<int, QI>{});
+  else if (nB == QI - 1) kloop(std::integral_constant<int, QI - 1>{});
+  else kloop(std::integral_constant<int, QI - 2>{});
+  }
 #undef WM_W2
-  if (wr == 0) __builtin_amdgcn_s_barrier();
+#ifdef WM_GEMM_STAMPS
+  const unsigned long long st_loop1 = __builtin_amdgcn_s_memrealtime(), st_cyc1 = __builtin_amdgcn_s_memtime();
+#endif
+  if (VER == 2 && wr == 0) __builtin_amdgcn_s_barrier();
   if (DBG == 5 && acc[0][0][0] != 1.2345e-30f) return;  // timing experiment: no epilogue
-  epilogue16<T, EPI, SM, SN>(p, acc, m0 + wr * WROWS, n0 + wc * 64, lane);
+  {
+    const int rowb = m0 + (wr ? 16 * S0 : 0), rend = rowb + 16 * Sw;
+    epilogue16<T, EPI, SM, SN>(p, acc, rowb, n0 + wc * 64, lane, rend < p.M ? rend : p.M);
+  }
+#ifdef WM_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wave == 0 && blockIdx.x < 8192) {
+    const unsigned long long st_exit = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_HW_ID, HW_REG_XCC_ID
+    if (lane == 0) {
+      unsigned long long* o = wm_gemm_stamp_buf + (size_t)blockIdx.x * 8;
+      o[0] = st_entry; o[1] = st_loop0; o[2] = st_loop1; o[3] = st_exit; o[4] = st_cyc1 - st_cyc0;
+      o[5] = ((unsigned long long)xcc << 32) | hw; o[6] = ((unsigned long long)m0 << 32) | (unsigned)n0; o[7] = 1;
+    }
+  }
+#endif
 }
 
-template <int T, int EPI, int DBG = 0, int QI = 4>
+template <int T, int EPI, int DBG = 0, int QI = 4, int VER = 2>
 hipError_t launch_pp2(const WmGemmArgs& a, hipStream_t s) {
   constexpr int BM = 64 * QI;
   constexpr size_t shm = (size_t)2 * (BM + 256) * 128;
-  const int ntn = (a.N + 255) / 256, ntm = (a.M + BM - 1) / BM;
+  const int ntn = (a.N + 255) / 256, ntm = a.sched_bands > 0 ? a.sched_bands : (a.M + BM - 1) / BM;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<T, EPI, 1, DBG, QI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)gemm_pp2_kernel<T, EPI, 1, DBG, QI, VER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_pp2_kernel<T, EPI, 1, DBG, QI>), dim3(ntm * ntn), dim3(512), shm, s, a);
+  hipLaunchKernelGGL((gemm_pp2_kernel<T, EPI, 1, DBG, QI, VER>), dim3(ntm * ntn), dim3(512), shm, s, a);
   return hipGetLastError();
 }
 
@@ -971,8 +1161,9 @@ hipError_t launch_pp(const WmGemmArgs& a, hipStream_t s) {
 
 template <int T, int EPI>
 hipError_t launch_pp_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
-  if (cfg == 4 && wm_tuning[WM_TUNE_GEMM_PP] != 3) return launch_pp2<T, EPI>(a, s);  // gemm_pp = 3 forces v1
-  if (cfg == 5 && wm_tuning[WM_TUNE_GEMM_PP] != 3) return launch_pp2<T, EPI, 0, 3>(a, s);
+  const int ver = wm_tuning[WM_TUNE_GEMM_PP];   // 2 = ping-pong v2 (a barrier on both sides of every MFMA stage), 3 = v1, else v3 (half the barriers)
+  if (ver == 2) return cfg == 4 ? launch_pp2<T, EPI>(a, s) : launch_pp2<T, EPI, 0, 3>(a, s);
+  if (ver != 3) return cfg == 4 ? launch_pp2<T, EPI, 0, 4, 3>(a, s) : launch_pp2<T, EPI, 0, 3, 3>(a, s);
   return cfg == 5 ? launch_pp<T, EPI, 3>(a, s) : launch_pp<T, EPI, 4>(a, s);
 }
 
@@ -1006,6 +1197,16 @@ hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
   if (pp > 10 && a.epi == WM_EPI_F32 && T == WM_T_BF16)
     if (pp == 14) return launch_pp2<T, WM_EPI_F32, 4>(a, s);
   if (pp == 15 && a.epi == WM_EPI_F32 && T == WM_T_BF16) return cfg == 5 ? launch_pp2<T, WM_EPI_F32, 5, 3>(a, s) : launch_pp2<T, WM_EPI_F32, 5>(a, s);
+  if (pp == 16 && a.epi == WM_EPI_F32 && T == WM_T_BF16) return cfg == 5 ? launch_pp2<T, WM_EPI_F32, 6, 3>(a, s) : launch_pp2<T, WM_EPI_F32, 6>(a, s);
+  if (pp >= 100 && pp < 116 && a.epi == WM_EPI_F32 && T == WM_T_BF16) {
+    switch (pp - 100) {
+#define WM_DBGM(m_) case m_: return cfg == 5 ? launch_pp2<T, WM_EPI_F32, 16 + m_, 3>(a, s) : launch_pp2<T, WM_EPI_F32, 16 + m_>(a, s);
+      WM_DBGM(1) WM_DBGM(2) WM_DBGM(4) WM_DBGM(8) WM_DBGM(3) WM_DBGM(7) WM_DBGM(15) WM_DBGM(5) WM_DBGM(12)
+#undef WM_DBGM
+      default: break;
+    }
+  }
+  if (pp == 17 && a.epi == WM_EPI_F32 && T == WM_T_BF16) return cfg == 5 ? launch_pp2<T, WM_EPI_F32, 4, 3>(a, s) : launch_pp2<T, WM_EPI_F32, 4>(a, s);
   if (pp > 10 && a.epi == WM_EPI_F32 && T == WM_T_BF16)
     return pp == 11 ? launch_pp<T, WM_EPI_F32, 4, 1>(a, s) : pp == 12 ? launch_pp<T, WM_EPI_F32, 4, 2>(a, s) : launch_pp<T, WM_EPI_F32, 4, 3>(a, s);
 #endif
@@ -1063,6 +1264,44 @@ int pick_cfg(const WmGemmArgs& a) {
   return best;
 }
 
+// Row-band schedule of the ping-pong v2 kernel (see gemm_pp2_kernel): how many row bands B to cut the M rows into, and on
+// which tile height (cfg 4 = up to 16 units of 16 rows, cfg 5 = up to 12).  Candidates are the B that fill R = 1, 2, ... whole
+// rounds of the CUs (B = floor(R ncu / ntn)) and the fewest bands the tile height allows; cost = rounds x one block's time,
+// with the block's time from profiles/r04_gemm_timeline.md (prologue 1.6 us; per 1024 of K the full tile's K loop takes
+// 1.5 us per 16-row unit on the 12-unit tile and 1.43 on the 16-unit one, but a unit CUT from a tile gives back only ~0.5 us:
+// the loop is bound by its LDS traffic, which does not shrink with the MFMAs; ~0.35 us of epilogue per unit).
+// forced_cfg >= 0 keeps the tile height.
+void pick_sched(const WmGemmArgs& a, int ncu, int forced_cfg, int& cfg, int& bands) {
+  const int U = (a.M + 15) / 16, ntn = (a.N + 255) / 256;
+  const float kf = (float)a.K / 1024.0f;
+  float best = 1e30f;
+  int best_cfg = cfg, best_b = 0;
+  for (int c = 4; c <= 5; ++c) {
+    if (forced_cfg >= 0 && c != forced_cfg) continue;
+    const int full = c == 4 ? 16 : 12;
+    const float unit = c == 4 ? 1.43f : 1.5f;
+    const int bmin = (U + full - 1) / full;
+    for (int k = 0; k < 6; ++k) {
+      int B;
+      if (k == 0) B = bmin;
+      else {
+        const long r0 = ((long)bmin * ntn + ncu - 1) / ncu;   // rounds of the fewest-bands candidate
+        B = (int)(((r0 + k - 1) * ncu) / ntn);
+      }
+      if (B < bmin) continue;
+      if (B > U) B = U;
+      const int smax = (U + B - 1) / B;
+      if (U / B < full - 4) continue;   // the kernel drops at most 2 units per wave group
+      const long rounds = ((long)B * ntn + ncu - 1) / ncu;
+      const float loop = kf * (full * unit - 0.5f * (float)(full - smax));
+      const float cost = (float)rounds * (1.6f + loop + 0.35f * (float)smax);
+      if (cost < best) { best = cost; best_cfg = c; best_b = B; }
+    }
+  }
+  cfg = best_cfg;
+  bands = best_b;
+}
+
 }  // namespace
 
 hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
@@ -1072,17 +1311,51 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
   if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
   if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
-  const int cfg = pick_cfg(a);
+  int cfg = pick_cfg(a);
+  int sched_b = 0;
+  {
+    // ping-pong v2 launches only (launch_T): backbone epilogues on the 256- / 192-row tiles
+    static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    const int pp = wm_tuning[WM_TUNE_GEMM_PP];
+    const bool pp2 = (cfg == 4 || cfg == 5) && (pp < 0 || pp == 1 || pp == 2) && (a.epi == WM_EPI_F32 || a.epi == WM_EPI_T16 || a.epi == WM_EPI_GELU_T16 || a.epi == WM_EPI_RESID || a.epi == WM_EPI_QKV);
+    const int ts = wm_tuning[WM_TUNE_GEMM_SCHED];   // -1 choose, 0 off (full-height tiles), > 0 that many bands
+    if (pp2 && ts != 0) {
+      // Measured (profiles/r04_gemm_timeline.md, `sched` rows): at M = 11008 the schedule takes 2.4 - 5.1 % off all four backbone
+      // GEMMs (2.7 -> 3.0 and 0.9 -> 1.0 rounds of shorter blocks); at M = 44032 (8 - 11 rounds, where a ragged last round
+      // costs at most a tenth) it measured +5 / +4 / +1.6 / -2.3 %.  So: only launches of at most three rounds.
+      const long legacy_tiles = (long)((a.M + (cfg == 4 ? 255 : 191)) / (cfg == 4 ? 256 : 192)) * ((a.N + 255) / 256);
+      if (ts > 0) sched_b = ts;
+      else if (legacy_tiles <= 3L * ncu && a.M <= 16384) pick_sched(a, ncu, wm_tuning[WM_TUNE_GEMM_CFG], cfg, sched_b);
+      const int U = (a.M + 15) / 16, full = cfg == 4 ? 16 : 12;
+      if (sched_b > U) sched_b = U;
+      // bands taller than the tile, or shorter than the kernel's instantiations go (a wave group drops at most 2 units): full-height grid
+      if (sched_b <= 0 || (U + sched_b - 1) / sched_b > full || U / sched_b < full - 4) sched_b = 0;
+    }
+  }
   const int gb = wm_tuning[WM_TUNE_GEMM_GROUP] >= 0 ? wm_tuning[WM_TUNE_GEMM_GROUP] : 6;  // row bands per supertile: 6 measured 2-3 % ahead of 4 / 8 at 32 views, equal at 8 (tools/bench_gemm_group.py)
   if (a.epi == WM_EPI_QKV) {
     if (a.qkv.tokens_per_view <= 0 || a.qkv.grid_w <= 0 || a.M >= (1 << 20) || a.qkv.tokens_per_view >= (1 << 16)) return hipErrorInvalidValue;
     WmGemmArgs b = a;
     b.group_bands = gb;
+    b.sched_bands = sched_b; b.sched_units = (a.M + 15) / 16;
     b.qkv.inv_tpv = 1.0f / (float)a.qkv.tokens_per_view;
     b.qkv.inv_gw = 1.0f / (float)a.qkv.grid_w;
     return b.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(b, cfg, s) : launch_T<WM_T_F16>(b, cfg, s);
   }
   WmGemmArgs c = a;
   c.group_bands = gb;
+  c.sched_bands = sched_b; c.sched_units = (a.M + 15) / 16;
   return c.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(c, cfg, s) : launch_T<WM_T_F16>(c, cfg, s);
 }
+
+#ifdef WM_GEMM_STAMPS
+extern "C" int wm_debug_gemm_stamps(unsigned long long* host_out, int nblocks) {
+  if (nblocks > 8192) nblocks = 8192;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wm_gemm_stamp_buf), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int wm_debug_gemm_stamps_clear() {
+  void* d = nullptr;
+  if (hipGetSymbolAddress(&d, HIP_SYMBOL(wm_gemm_stamp_buf)) != hipSuccess) return 1;
+  return hipMemset(d, 0, sizeof(unsigned long long) * 8 * 8192) == hipSuccess ? 0 : 1;
+}
+#endif

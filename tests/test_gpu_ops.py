@@ -76,6 +76,83 @@ def test_gemm_epilogues(dev, M, N, K, dt):
     assert _rel(X, X0 + gamma * ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(11008, 1024, 1024), (11008, 3072, 256), (2752, 1024, 512), (1376 * 3 + 5, 512, 256), (200, 256, 128)])
+@pytest.mark.parametrize("cfg", [4, 5])
+def test_gemm_row_band_schedule_is_bit_identical(dev, M, N, K, cfg):
+    """gemm_pp2_kernel with the M rows cut into bands of unequal height (wm_launch_gemm's schedule, or a forced band count) must
+    give the same bits as the full-height grid: a band only changes WHICH block owns a row, not the order its K sum runs in."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + cfg)
+    A = _t16(torch.randn(M, K, generator=g), BF16).to(dev)
+    W = _t16(torch.randn(N, K, generator=g) / math.sqrt(K), BF16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    gamma = torch.randn(N, generator=g).to(dev)
+    X0 = torch.randn(M, N, generator=g).to(dev)
+    L = _lib()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    U, full = (M + 15) // 16, 16 if cfg == 4 else 12
+    bmin = (U + full - 1) // full
+    forced = sorted({bmin, bmin + 1, min(U, bmin * 2 - 1), min(U, (bmin * 3) // 2 + 1)})
+
+    def run(sched):
+        assert L.wm_set_tuning(b"gemm_cfg", cfg) == 0 and L.wm_set_tuning(b"gemm_sched", sched) == 0
+        try:
+            f32 = torch.empty(M, N, device=dev)
+            o16 = torch.empty(M, N, device=dev, dtype=torch.int16)
+            ge = torch.empty(M, N, device=dev, dtype=torch.int16)
+            X = X0.clone()
+            assert L.wm_op_gemm(BF16, 0, _p(A), _p(W), _p(f32), _p(bias), None, M, N, K, s) == 0
+            assert L.wm_op_gemm(BF16, 1, _p(A), _p(W), _p(o16), _p(bias), None, M, N, K, s) == 0
+            assert L.wm_op_gemm(BF16, 2, _p(A), _p(W), _p(ge), _p(bias), None, M, N, K, s) == 0
+            assert L.wm_op_gemm(BF16, 3, _p(A), _p(W), _p(X), _p(bias), _p(gamma), M, N, K, s) == 0
+            torch.cuda.synchronize()
+            return f32, o16, ge, X
+        finally:
+            L.wm_set_tuning(b"gemm_cfg", -1); L.wm_set_tuning(b"gemm_sched", -1)
+
+    base = run(0)   # full-height tiles
+    assert _rel(base[0], A.float() @ W.float().t() + bias) < 2e-5
+    for sched in [-1] + forced:
+        got = run(sched)
+        for name, a, b in zip(("f32", "t16", "gelu", "resid"), got, base):
+            assert torch.equal(a, b), f"{name} differs with gemm_sched={sched} (M={M}, cfg={cfg})"
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 448, 1024, 4096])
+@pytest.mark.parametrize("cfg", [4, 5])
+def test_gemm_pingpong_v3_matches_v2_bitwise(dev, K, cfg):
+    """The half-the-barriers schedule (gemm_pp2_kernel VER = 3, the default) against the two-barriers-per-stage one (gemm_pp = 2):
+    same MFMAs in the same order, so any difference is a synchronisation fault (a fragment read before its LDS-DMA landed, or a
+    region refilled while a wave still read it).  K from one K-tile up (the prologue / tail branches of the counted waits), both
+    tile heights, odd row counts, several launches back to back."""
+    L = _lib()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for M, N in ((11008, 1024), (5000, 768), (1376 * 2 + 3, 256)):
+        g = torch.Generator(device="cpu").manual_seed(M + K + cfg)
+        A = _t16(torch.randn(M, K, generator=g), BF16).to(dev)
+        W = _t16(torch.randn(N, K, generator=g) / math.sqrt(K), BF16).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        outs = {}
+        for ver in (2, -1):
+            assert L.wm_set_tuning(b"gemm_cfg", cfg) == 0 and L.wm_set_tuning(b"gemm_pp", ver) == 0
+            try:
+                res = []
+                for rep in range(4 if ver == -1 else 1):
+                    f32 = torch.empty(M, N, device=dev)
+                    ge = torch.empty(M, N, device=dev, dtype=torch.int16)
+                    assert L.wm_op_gemm(BF16, 0, _p(A), _p(W), _p(f32), _p(bias), None, M, N, K, s) == 0
+                    assert L.wm_op_gemm(BF16, 2, _p(A), _p(W), _p(ge), _p(bias), None, M, N, K, s) == 0
+                    res.append((f32, ge))
+                torch.cuda.synchronize()
+                outs[ver] = res
+            finally:
+                L.wm_set_tuning(b"gemm_cfg", -1); L.wm_set_tuning(b"gemm_pp", -1)
+        ref32, refge = outs[2][0]
+        assert _rel(ref32, A.float() @ W.float().t() + bias) < 2e-5
+        for rep, (f32, ge) in enumerate(outs[-1]):
+            assert torch.equal(f32, ref32), f"f32 differs: M={M} N={N} K={K} cfg={cfg} rep={rep}"
+            assert torch.equal(ge, refge), f"gelu differs: M={M} N={N} K={K} cfg={cfg} rep={rep}"
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed C-write (guides §3)."""
     K = N = 128
