@@ -74,6 +74,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
   __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * TILE_B];  // [buf][K|V]
 
   if (p.only_if && p.only_if[blockIdx.x] == 0) return;  // recompute pass behind attn_v3_kernel: only the blocks it flagged (block-uniform)
+  if (p.only_if && p.unit_hint && threadIdx.x == 0) {    // sticky hint: one call of this unit on the general kernel used up (nothing here reads the hint)
+    const int hv = p.unit_hint[blockIdx.x];
+    if (hv > 0) p.unit_hint[blockIdx.x] = hv - 1;
+  }
+  if (p.only_if && p.unit_stat && threadIdx.x == 0) atomicAdd(p.unit_stat, 1);   // units taken by the recompute pass, for the host's policy
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, ql = lane & 31;
   const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
@@ -740,13 +745,18 @@ hipError_t launch(const WmAttnArgs& a_in, hipStream_t s, int fast = 0) {   // fa
   const int nfull = a.kv_splits > 1 ? a.full_units : units;
   dim3 grid(nfull + (units - nfull) * a.kv_splits), block(NW * 64);
   if (use_v3) {  // same unit / split numbering (QT = 256 / 512): the fast kernel, then the general kernel on the blocks it flagged
-    static const int v3_minw = [] { const char* e = getenv("WM_ATTN_V3_MINW"); return e ? atoi(e) : 2; }();
+    static const int v3_minw = [] { const char* e = wm_env("WM_ATTN_V3_MINW"); return e ? atoi(e) : 2; }();
     hipError_t e = fast == 4 ? wm_launch_attention_v4(a, (int)grid.x, a.unit_flags, s) : wm_launch_attention_v3(a, (int)grid.x, a.unit_flags, v3_minw, s);
     if (e != hipSuccess) return e;
     a.only_if = a.unit_flags;
   }
-  // (timing-only switch for tools/attn_launch_cost.py: 1 skips the recompute pass behind a fast kernel, 2 the combine pass, 3 both — wrong results)
-  static const int dbg_skip = [] { const char* e = getenv("WM_ATTN_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
+#ifdef WM_ATTN_TIMING_EXPERIMENT
+  // (timing-only build for tools/attn_launch_cost.py, make EXTRA="-DWM_ATTN_TIMING_EXPERIMENT -DWM_DIAG_ENV": 1 skips the recompute pass behind
+  //  a fast kernel, 2 the combine pass, 3 both — wrong results; not in the shipped library)
+  static const int dbg_skip = [] { const char* e = wm_env("WM_ATTN_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int dbg_skip = 0;
+#endif
   if (!(use_v3 && (dbg_skip & 1))) hipLaunchKernelGGL((attn_fwd_kernel<T, NW, QB, MINW, LZ, STG>), grid, block, 0, s, a);
   if (a.kv_splits > 1 && !a.force_partial && !(dbg_skip & 2))
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((units - nfull) * (QT / 16))), dim3(256), 0, s, a, QT);
@@ -776,9 +786,9 @@ hipError_t wm_launch_attention_combine(const WmAttnArgs& a_in, int slots, hipStr
 //   3  general kernel (integer running max), 64 rows per wave at 2 waves / SIMD: everything else on long sequences, and every
 //      piecewise (force_partial) launch that is not 7 / 8
 //   4  general kernel, 32 rows per wave at 3 waves / SIMD: the short per-frame / DINO sequences
-// 7 and 8 need a flag workspace and key segments of whole 64-key tiles (>= 512 keys); other values: A/B variants (forced only).
+// 7 and 8 need a flag workspace and key segments of >= 512 keys (a ragged last tile is padded with zero keys); other values: A/B variants (forced only).
 int wm_attention_variant(const WmAttnArgs& a) {
-  static const int forced_env = [] { const char* e = getenv("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
+  static const int forced_env = [] { const char* e = wm_env("WM_ATTN_QB"); return e ? atoi(e) : 0; }();
   const int forced = wm_tuning[WM_TUNE_ATTN_QB] >= 0 ? wm_tuning[WM_TUNE_ATTN_QB] : forced_env;
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;
   const bool fast_ok = a.unit_flags != nullptr && seg_rows >= 512;   // (a ragged last tile is padded with zero keys)
@@ -807,15 +817,11 @@ void wm_attention_geometry(const WmAttnArgs& a, int* unit_rows, int* blocks_per_
 hipError_t wm_launch_attention(const WmAttnArgs& a, hipStream_t s) {
   if (a.q_rows <= 0) return hipSuccess;
   if (a.seq_len <= 0 || a.q_rows % a.seq_len != 0 || a.kv_chunks < 1) return hipErrorInvalidValue;
-  // 64 rows per wave at 2 waves/SIMD with the lazy max for the long cross-view sequences; the short per-frame / DINO sequences
-  // (22 key tiles) run 3-10 % faster as 128-row blocks of 32 rows per wave at 3 waves/SIMD (finer q-tiles: 10.75 -> 11 instead
-  // of 5.4 -> 6 per frame, and more waves to overlap; tools/bench_attn_qb.py: 84 vs 87 us at 8 views, 287 vs 313 us at 32)
-  // The software-pipelined no-max kernel (7, attention_v3.hip) for bf16 with a flag workspace and key segments of whole
-  // 64-key tiles (the cross-view sequences) — else the general kernel: 64 rows per wave at 2 waves / SIMD (3) for long
-  // sequences, 32 rows per wave at 3 waves / SIMD (4) for the short per-frame / DINO ones.
-  // tools/bench_attn_v3.py: 1085 vs 820-930 TF/s at 8 views, 1240 vs 1117 at 32 views.  The per-frame / DINO sequences
-  // (1376 / 1374 keys = 21.5 tiles) have a ragged last tile: the v3 instantiation that masks it needs one wave per SIMD and
-  // loses to (4) there (122 vs 86 us at 8 views), so it runs only when forced (WM_ATTN_QB=7 / tuning: the parity tests do).
+  // Which kernel runs is decided by wm_attention_variant (above): attn_v4 (8) on every long sequence with a flag workspace, attn_v3 (7)
+  // on the per-frame sequences from 16 frames up (bf16), the general kernel at 32 rows per wave and 3 waves / SIMD (4) on the
+  // short per-frame / DINO sequences below that, at 64 rows per wave and 2 waves / SIMD (3) otherwise.  The fast kernels flag the
+  // units that left their range; the general kernel recomputes exactly those (and a unit's sticky hint, WmAttnArgs::unit_hint,
+  // sends it there directly on the following calls).
   const int qb = wm_attention_variant(a);
   if (qb < 0) return hipErrorInvalidValue;
   const int seg_rows = a.kv_chunks > 1 ? a.kv_rows_per_chunk : a.seq_len;

@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   constexpr int VBASE = KRING * TILE_B;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.unit_hint && p.unit_hint[blockIdx.x] > 0) {   // block-uniform: see attention_v4.hip / WmAttnArgs::unit_hint
+    if (tid == 0) flags[blockIdx.x] = 17;
+    return;
+  }
   const int h = lane >> 5, ql = lane & 31;
   const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
   const int nseq = p.q_rows / p.seq_len;
@@ -395,7 +399,11 @@ __global__ __launch_bounds__(256, MINW) void attn_v3_kernel(const WmAttnArgs p, 
   __shared__ int bad_sh[4];
   if (lane == 0) bad_sh[wave] = any_bad;
   __syncthreads();
-  if (tid == 0) flags[blockIdx.x] = bad_sh[0] | bad_sh[1] | bad_sh[2] | bad_sh[3];
+  if (tid == 0) {
+    const int f = bad_sh[0] | bad_sh[1] | bad_sh[2] | bad_sh[3];
+    flags[blockIdx.x] = f;
+    if (f && p.unit_hint) p.unit_hint[blockIdx.x] = WM_ATTN_HINT_TTL + 1;
+  }
 
   if (nsplit > 1 || p.force_partial) {  // unnormalised partial (running max 0): the combine pass finishes the softmax
     const int slot = p.part_slot0 + split;

@@ -195,6 +195,10 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.unit_hint && p.unit_hint[blockIdx.x] > 0) {   // block-uniform: this unit left the fast range in a recent call — straight to the general kernel
+    if (tid == 0) flags[blockIdx.x] = 17;            // (16: by hint; nothing in this kernel writes the hint before its flag write at the end)
+    return;
+  }
   const int h = lane >> 5, ql = lane & 31;
   const int tiles_per_seq = (p.seq_len + QT - 1) / QT;
   const int nseq = p.q_rows / p.seq_len;
@@ -628,7 +632,11 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
   __shared__ int bad_sh[4];
   if (lane == 0) bad_sh[wave] = any_bad;
   __syncthreads();
-  if (tid == 0) { const int f = bad_sh[0] | bad_sh[1] | bad_sh[2] | bad_sh[3]; flags[blockIdx.x] = f ? (f | 1) : 0; }
+  if (tid == 0) {
+    const int f = bad_sh[0] | bad_sh[1] | bad_sh[2] | bad_sh[3];
+    flags[blockIdx.x] = f ? (f | 1) : 0;
+    if (f && p.unit_hint) p.unit_hint[blockIdx.x] = WM_ATTN_HINT_TTL + 1;   // (+1: the recompute pass of this very call counts it down once)
+  }
 
   if (nsplit > 1 || p.force_partial) {  // unnormalised partial (running max m_run): the combine pass finishes the softmax
     const int slot = p.part_slot0 + split;

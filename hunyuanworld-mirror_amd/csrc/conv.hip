@@ -213,7 +213,7 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
     static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
     const long M = (long)a.N * a.Ho * a.Wo;
     const long t128 = ((M + 127) / 128) * ((a.Cout + 127) / 128);
-    static const int bm_env = [] { const char* e = getenv("WM_CONV_BM"); return e ? atoi(e) : 0; }();
+    static const int bm_env = [] { const char* e = wm_env("WM_CONV_BM"); return e ? atoi(e) : 0; }();
     if (!narrow && (bm_env == 64 || (bm_env == 0 && t128 < ncu))) return launch_cfg<T, 64, 2, 2, 1, 2>(a, s);
     return narrow ? launch_cfg<T, 64, 4, 1, 1, 1>(a, s) : launch_cfg<T, 64, 2, 2, 2, 2>(a, s);
   } else {

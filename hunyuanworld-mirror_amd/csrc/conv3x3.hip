@@ -732,7 +732,7 @@ hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
 }  // namespace
 
 bool wm_conv_force_generic() {  // WM_CONV_GENERIC (A/B switch): every conv through the generic kernel of conv.hip
-  static const bool g = getenv("WM_CONV_GENERIC") != nullptr;
+  static const bool g = wm_env("WM_CONV_GENERIC") != nullptr;
   return g;
 }
 bool wm_conv3x3_out16_ok(const WmConvArgs& a) {  // exactly the launches launch_T sends to conv3x3_rs_kernel with a plain input
@@ -746,7 +746,7 @@ bool wm_conv3x3_applicable(const WmConvArgs& a) {
 hipError_t wm_launch_conv3x3(const WmConvArgs& a_in, hipStream_t s) {
   WmConvArgs a = a_in;
 #ifdef WM_CONV_TIMING_EXPERIMENT
-  { const char* e = getenv("WM_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
+  { const char* e = wm_env("WM_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
 #else
   a.dbg = 0;
 #endif

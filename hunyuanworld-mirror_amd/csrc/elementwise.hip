@@ -532,7 +532,7 @@ hipError_t wm_launch_im2col(const float* img, void* out, int N, int C, int H, in
                             int dtype, hipStream_t s) {
   const size_t total = (size_t)N * (H / ps) * (W / ps) * Kpad;
   if (!total) return hipSuccess;
-  static const bool rows_env = [] { const char* e = getenv("WM_IM2COL_ROWS"); return !e || atoi(e) != 0; }();
+  static const bool rows_env = [] { const char* e = wm_env("WM_IM2COL_ROWS"); return !e || atoi(e) != 0; }();
   const size_t lds = (size_t)ps * W * sizeof(u16);
   if (rows_env && ps % 2 == 0 && W % 2 == 0 && (C * ps * ps) % 2 == 0 && Kpad % 2 == 0 && lds <= 64 * 1024) {   // input-indexed form (coalesced image reads)
     const dim3 grid((unsigned)(N * (H / ps) * C));
@@ -559,7 +559,7 @@ hipError_t wm_launch_gs_splat(const float* gp, const float* img, const float* de
                               float* scales, float* opac, float* sh, float* wts, int N, int H, int W, hipStream_t s) {
   if (!N) return hipSuccess;
 #ifdef WM_DBG_SPLAT_BUILD
-  static const int dbg = getenv("WM_DBG_SPLAT") ? 1 : 0;
+  static const int dbg = wm_env("WM_DBG_SPLAT") ? 1 : 0;
 #else
   const int dbg = 0;
 #endif
@@ -595,7 +595,7 @@ hipError_t wm_launch_bilinear(const float* in, float* out, int N, int Hi, int Wi
   if (C % 8) return hipErrorInvalidValue;
   const size_t total = (size_t)N * Ho * Wo * (C / 4);
   if (!total) return hipSuccess;
-  static const int tiled_env = [] { const char* e = getenv("WM_BILINEAR_TILED"); return e ? atoi(e) : 1; }();
+  static const int tiled_env = [] { const char* e = wm_env("WM_BILINEAR_TILED"); return e ? atoi(e) : 1; }();
   if (tiled_env && bilinear_tiled_ok(Hi, Wi, Ho, Wo, C)) {
     hipLaunchKernelGGL(bilinear_tiled_kernel<0>, dim3((unsigned)(N * ((Ho + 15) / 16) * ((Wo + 15) / 16))), dim3(256), 0, s, in, (void*)out, N, Hi, Wi, Ho, Wo, C, addx, addy);
     return hipGetLastError();
@@ -609,7 +609,7 @@ hipError_t wm_launch_bilinear16(const float* in, void* out16, int N, int Hi, int
   if (C % 4) return hipErrorInvalidValue;
   const size_t total = (size_t)N * Ho * Wo * (C / 4);
   if (!total) return hipSuccess;
-  static const int tiled_env = [] { const char* e = getenv("WM_BILINEAR_TILED"); return e ? atoi(e) : 1; }();
+  static const int tiled_env = [] { const char* e = wm_env("WM_BILINEAR_TILED"); return e ? atoi(e) : 1; }();
   if (tiled_env && bilinear_tiled_ok(Hi, Wi, Ho, Wo, C)) {
     const dim3 grid((unsigned)(N * ((Ho + 15) / 16) * ((Wo + 15) / 16)));
     if (dtype == WM_T_BF16) hipLaunchKernelGGL(bilinear_tiled_kernel<1>, grid, dim3(256), 0, s, in, out16, N, Hi, Wi, Ho, Wo, C, addx, addy);

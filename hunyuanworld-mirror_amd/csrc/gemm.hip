@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -1161,9 +1161,11 @@ hipError_t launch_pp(const WmGemmArgs& a, hipStream_t s) {
 
 template <int T, int EPI>
 hipError_t launch_pp_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
-  const int ver = wm_tuning[WM_TUNE_GEMM_PP];   // 2 = ping-pong v2 (a barrier on both sides of every MFMA stage), 3 = v1, else v3 (half the barriers)
-  if (ver == 2) return cfg == 4 ? launch_pp2<T, EPI>(a, s) : launch_pp2<T, EPI, 0, 3>(a, s);
-  if (ver != 3) return cfg == 4 ? launch_pp2<T, EPI, 0, 4, 3>(a, s) : launch_pp2<T, EPI, 0, 3, 3>(a, s);
+  // gemm_pp tuning: 3 = v1, 4 = v3 (half the barriers: bit-identical, measured +0.1 - 0.3 % on the forward, i.e. nothing — kept
+  // selectable and under test as the record of that experiment), anything else = v2 (a barrier on both sides of every MFMA stage)
+  const int ver = wm_tuning[WM_TUNE_GEMM_PP];
+  if (ver == 4) return cfg == 4 ? launch_pp2<T, EPI, 0, 4, 3>(a, s) : launch_pp2<T, EPI, 0, 3, 3>(a, s);
+  if (ver != 3) return cfg == 4 ? launch_pp2<T, EPI>(a, s) : launch_pp2<T, EPI, 0, 3>(a, s);
   return cfg == 5 ? launch_pp<T, EPI, 3>(a, s) : launch_pp<T, EPI, 4>(a, s);
 }
 
@@ -1189,8 +1191,8 @@ template <int T>
 hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
   // 16x16x32 MFMA main loop: measured +3..8 % on the N=1024 GEMMs (proj, fc2) and +0..2 % on QKV, neutral/negative
   // on fc1 (tools/bench_gemm.py); WM_GEMM_MFMA16 = 0 / 2 forces it off / on for every backbone epilogue
-  static const int mf16_env = [] { const char* e = getenv("WM_GEMM_MFMA16"); return e ? atoi(e) : 1; }();
-  static const int pp_env = [] { const char* e = getenv("WM_GEMM_PP"); return e ? atoi(e) : 1; }();
+  static const int mf16_env = [] { const char* e = wm_env("WM_GEMM_MFMA16"); return e ? atoi(e) : 1; }();
+  static const int pp_env = [] { const char* e = wm_env("WM_GEMM_PP"); return e ? atoi(e) : 1; }();
   const int mf16 = wm_tuning[WM_TUNE_GEMM_MFMA16] >= 0 ? wm_tuning[WM_TUNE_GEMM_MFMA16] : mf16_env;
   const int pp = wm_tuning[WM_TUNE_GEMM_PP] >= 0 ? wm_tuning[WM_TUNE_GEMM_PP] : pp_env;
 #ifdef WM_GEMM_PP_DEBUG  // timing experiments only (results are wrong): 11 no DMA, 12 no ds_read, 13 no barriers
@@ -1243,7 +1245,7 @@ hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
 }
 
 int pick_cfg(const WmGemmArgs& a) {
-  static const int forced = [] { const char* e = getenv("WM_GEMM_CFG"); return e ? atoi(e) : -1; }();
+  static const int forced = [] { const char* e = wm_env("WM_GEMM_CFG"); return e ? atoi(e) : -1; }();
   if (wm_tuning[WM_TUNE_GEMM_CFG] >= 0) return wm_tuning[WM_TUNE_GEMM_CFG];
   if (forced >= 0) return forced;
   if (a.M <= 128 || a.N <= 128) return 0;
@@ -1317,7 +1319,7 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
     // ping-pong v2 launches only (launch_T): backbone epilogues on the 256- / 192-row tiles
     static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
     const int pp = wm_tuning[WM_TUNE_GEMM_PP];
-    const bool pp2 = (cfg == 4 || cfg == 5) && (pp < 0 || pp == 1 || pp == 2) && (a.epi == WM_EPI_F32 || a.epi == WM_EPI_T16 || a.epi == WM_EPI_GELU_T16 || a.epi == WM_EPI_RESID || a.epi == WM_EPI_QKV);
+    const bool pp2 = (cfg == 4 || cfg == 5) && (pp < 0 || pp == 1 || pp == 2 || pp == 4) && (a.epi == WM_EPI_F32 || a.epi == WM_EPI_T16 || a.epi == WM_EPI_GELU_T16 || a.epi == WM_EPI_RESID || a.epi == WM_EPI_QKV);
     const int ts = wm_tuning[WM_TUNE_GEMM_SCHED];   // -1 choose, 0 off (full-height tiles), > 0 that many bands
     if (pp2 && ts != 0) {
       // Measured (profiles/r04_gemm_timeline.md, `sched` rows): at M = 11008 the schedule takes 2.4 - 5.1 % off all four backbone

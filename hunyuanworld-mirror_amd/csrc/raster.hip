@@ -354,7 +354,7 @@ hipError_t wm_launch_rasterize(const WmRasterArgs& a, hipStream_t s, unsigned lo
   // pixels per lane of the compositing pass: a whole tile per wave when that still gives every SIMD several waves, half a tile
   // otherwise (8 views at 518^2, 8 712 tiles: 4 / 2 / 1 pixels per lane 3.14 / 3.31 / 4.37 ms; 2 views, 2 178 tiles: end to end
   // 0.87 / 0.74 / 0.79 ms; the LDS-staged workgroup-per-tile form it replaces: 3.70 ms, 0.83 ms — profiles/r03_raster_ab.md)
-  static const int ppl_env = [] { const char* e = getenv("WM_RASTER_PPL"); return e ? atoi(e) : 0; }();   // A/B: 1, 2, 4
+  static const int ppl_env = [] { const char* e = wm_env("WM_RASTER_PPL"); return e ? atoi(e) : 0; }();   // A/B: 1, 2, 4
   const int ppl = ppl_env ? ppl_env : ((long)tiles * C >= 8192 ? 4 : 2);
   if (ppl == 1)
     hipLaunchKernelGGL((raster_composite_kernel<1, 1>), dim3((unsigned)tiles, (unsigned)C), dim3(256), 0, s, w.g2d, sorted_vals, w.tile_offs, tw, th, a.width,

@@ -357,7 +357,7 @@ hipError_t wm_launch_linear_f32(const float* X, const float* W, const float* b, 
 #define WM_STREAM(MT)                                                                                              \
   hipLaunchKernelGGL((linear_f32_stream_kernel<MT, 4>), dim3((N + 3) / 4, (M + MT - 1) / MT), dim3(256), 0, s, X, W, b, Y, \
                      M, N, K, ldx, ldy, pre_act, post_act, gamma, accumulate)
-    static const int nc_force = [] { const char* e = getenv("WM_LIN_NC"); return e ? atoi(e) : 0; }();
+    static const int nc_force = [] { const char* e = wm_env("WM_LIN_NC"); return e ? atoi(e) : 0; }();
     const int nc = nc_force ? nc_force : 2;  // measured best (tools/bench_lin.py): ~2 TB/s
     if (M <= 8 && nc == 8) {
       hipLaunchKernelGGL((linear_f32_stream_kernel<8, 8>), dim3((N + 7) / 8, 1), dim3(256), 0, s, X, W, b, Y, M, N, K, ldx, ldy,

@@ -4,6 +4,19 @@
 #include <stdint.h>
 #include <stddef.h>
 
+// The shipped library reads NO environment variable: kernel variants are chosen by the launchers and, for tests and A/B tools,
+// through wm_set_tuning.  The historical WM_* environment switches only exist in diagnostic builds (make EXTRA=-DWM_DIAG_ENV).
+#include <cstdlib>
+inline const char* wm_env(const char* name) {
+#ifdef WM_DIAG_ENV
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
+
 // ------------------------------------------------------------------ GEMM (gemm.hip)
 enum {
   WM_EPI_F32 = 0,         // C f32 = acc + bias
@@ -67,6 +80,18 @@ struct WmAttnArgs {
   // and recomputes exactly those blocks.  unit_flags null = general kernel only.
   int* unit_flags;
   const int* only_if;  // set by the launcher
+  // Sticky fallback hint (round 4), int[grid blocks] that PERSISTS across calls of the same call site (same shapes), or null: a unit
+  // the fast kernel had to flag is remembered (hint = WM_ATTN_HINT_TTL); while its hint is > 0 the fast kernel's block exits at entry
+  // (flag set) and only the general kernel computes the unit, which also counts the hint down — so a checkpoint whose scores leave the
+  // no-max range on some units (attention sinks) pays the general kernel for those units, not fast + general, and the fast kernel
+  // is tried again every WM_ATTN_HINT_TTL + 1 calls.  Correctness never depends on the hint's content: a flagged unit is always
+  // recomputed by the general kernel.
+  int* unit_hint;
+  // one device counter per call site, or null: every unit the recompute pass takes adds 1 (never reset).  The host reads it back
+  // asynchronously (a D2H copy at the end of the forward, no synchronisation) and, when a quarter or more of a site's units went to
+  // the general kernel, launches ONLY the general kernel there for the next WM_ATTN_HINT_TTL calls: two partly filled launches
+  // (fast kernel on the units in range, general kernel on the rest) cost up to 1.25 x the general kernel alone.
+  int* unit_stat;
   // Key range processed piecewise (sharded forward with the K/V all-gather overlapped, wm_model.cpp): with force_partial every
   // unit — split or not — writes an unnormalised partial into slot part_slot0 + split (kv_splits = the explicit, uniform slice
   // count of THIS launch, >= 1), nothing is combined; wm_launch_attention_combine then finishes all units over all slots.
@@ -86,6 +111,7 @@ inline size_t wm_attention_max_blocks(int q_rows, int seq_len, int H) {
   return ((size_t)(seq_len + 127) / 128 + 1) * nseq * (size_t)H * WM_ATTN_MAX_SPLITS_C;
 }
 constexpr int WM_ATTN_MAX_SPLITS = 8;
+constexpr int WM_ATTN_HINT_TTL = 15;
 
 // ------------------------------------------------------------------ elementwise (elementwise.hip)
 // LayerNorm over the last dim with row remapping: out row (g*out_group + out_off + q) <- in row
@@ -208,6 +234,6 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
                               const float* weights, int N, float voxel, float* o_means, float* o_quats, float* o_scales, float* o_opac,
                               float* o_sh, int* K_out, void* workspace, size_t ws_bytes, hipStream_t s);
 
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

@@ -92,6 +92,11 @@ struct wm_handle {
   // the camera head (HBM-bound weight streaming) runs beside the DPT heads (MFMA-bound) on its own queue
   hipStream_t camstream = nullptr;
   hipEvent_t camjoin = nullptr;
+  // fast-attention fallback statistics per call site (WmAttnArgs::unit_stat): pinned host copy written by an async D2H at the end of
+  // every forward, the last value seen per site, and the calls left in general-kernel-only mode
+  int* att_stat_host = nullptr;
+  int att_stat_n = 0;
+  std::vector<int> att_seen, att_general_ttl;
   // profiling
   bool prof = false;
   static constexpr int NKIND = 13;
@@ -282,6 +287,10 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   add("ATT_PO", (size_t)WM_ATTN_MAX_SPLITS * Mx * D * 4);   // split-KV attention partials (tail round of a launch cut into up to 8 key slices; uniform 4-way split when a sharded launch fits one round): unnormalised O, (max, sum)
   add("ATT_ML", (size_t)WM_ATTN_MAX_SPLITS * Mx * (D / 64) * 2 * 4);
   add("ATT_FLAGS", wm_attention_max_blocks((int)Mx, d.P < d.Td ? d.P : d.Td, d.heads) * 4);  // per-block fallback flags of the no-max attention kernel
+  // sticky fallback hints of the fast attention kernels (WmAttnArgs::unit_hint): one int per launch block, per attention call site
+  // (DINO + frame + global blocks) x up to 3 launches (the piecewise form under the overlapped gather); zeroed by wm_reserve
+  add("ATT_HINT", (size_t)(c.dino_depth + 2 * c.depth) * 3 * wm_attention_max_blocks((int)Mx, d.P < d.Td ? d.P : d.Td, d.heads) * 4);
+  add("ATT_STAT", (size_t)(c.dino_depth + 2 * c.depth) * 3 * 4);   // WmAttnArgs::unit_stat, one counter per (call site, launch)
   add("ZERO256", 256);  // zero page for the out-of-image halo pieces of the DMA-fed conv (conv_n32.hip); cleared at the start of every forward
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
   add("rope_sin", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
@@ -431,7 +440,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -468,6 +477,7 @@ extern "C" void wm_destroy(wm_handle* h) {
     if (h->hstream[i]) (void)hipStreamDestroy(h->hstream[i]);
     if (h->hjoin[i]) (void)hipEventDestroy(h->hjoin[i]);
   }
+  if (h->att_stat_host) (void)hipHostFree(h->att_stat_host);
   if (h->hfork) (void)hipEventDestroy(h->hfork);
   if (h->camstream) (void)hipStreamDestroy(h->camstream);
   if (h->camjoin) (void)hipEventDestroy(h->camjoin);
@@ -652,6 +662,21 @@ wm_status plan(wm_handle* h, const Dims& d) {
     HIPCHK(h, hipMemcpy(h->buf["rope_cos"], cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->buf["rope_sin"], sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
   }
+  {  // fallback statistics: counters at 0, host mirror allocated once (pinned: the forward copies into it without synchronising)
+    const int n = (c.dino_depth + 2 * c.depth) * 3;
+    if (h->att_stat_n != n) {
+      if (h->att_stat_host) HIPCHK(h, hipHostFree(h->att_stat_host));
+      h->att_stat_host = nullptr;
+      HIPCHK(h, hipHostMalloc((void**)&h->att_stat_host, (size_t)n * 4, hipHostMallocDefault));
+      h->att_stat_n = n;
+    }
+    memset(h->att_stat_host, 0, (size_t)n * 4);
+    h->att_seen.assign(n, 0);
+    h->att_general_ttl.assign(n, 0);
+    HIPCHK(h, hipMemset(h->buf["ATT_STAT"], 0, (size_t)n * 4));
+  }
+  // the fast attention kernels' sticky fallback hints start empty for a new shape (they index launch blocks)
+  HIPCHK(h, hipMemset(h->buf["ATT_HINT"], 0, (size_t)(c.dino_depth + 2 * c.depth) * 3 * wm_attention_max_blocks((int)d.Mx, d.P < d.Td ? d.P : d.Td, d.heads) * 4));
   // DINO pos-embed for this grid (vision_transformer.py:175-207)
   {
     const Weight* pe = W(h, "visual_geometry_transformer.patch_embed.pos_embed");
@@ -744,6 +769,7 @@ wm_status comm_allgather(wm_handle* h, const void* send, void* recv, size_t byte
 // ---------------------------------------------------------------- building blocks
 struct Ctx {
   wm_handle* h; Dims d; hipStream_t s; int bdt, hdt;
+  int attn_site = 0;   // attention call sites passed so far in this forward (index of the site's sticky fallback hints, ATT_HINT)
 };
 
 #define LCHK(c, e)                                                                                            \
@@ -811,16 +837,31 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
     WmAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.Q = Q16; a.O = O16; a.H = heads; a.q_rows = M; a.q_head_stride = M; a.dtype = dt;
-    static const bool force_gather = getenv("WM_FORCE_GATHER") != nullptr;  // 1-rank test of the collective path
+    const bool force_gather = wm_tuning[WM_TUNE_FORCE_GATHER] > 0;  // 1-rank test of the collective path (tests/test_gpu_sharded.py)
     // Opt-in (WM_COMM_OVERLAP=1 / tuning comm_overlap = 1; default: the gather on the compute queue): the overlapped form is
     // exercised by 8 in-process ranks on one GPU (tests/test_gpu_fullsize.py), but RCCL has not run it on real links yet
     // (no multi-GPU node was available to any round): the simpler event-free path is the default until one 8-GPU run of both,
     // compared bit for bit, is on record.  The second queue is safe here: between fork and join the compute queue runs only
     // the attention kernels, which contain no packed-fp32 instruction (the hazard described at the DPT heads below needs one;
     // tests/test_kernel_resources_cpu.py disassembles them)
-    static const bool overlap_env = [] { const char* e = getenv("WM_COMM_OVERLAP"); return e && atoi(e) != 0; }();
+    static const bool overlap_env = [] { const char* e = wm_env("WM_COMM_OVERLAP"); return e && atoi(e) != 0; }();
     a.part_o = B<float>(h, "ATT_PO"); a.part_ml = B<float>(h, "ATT_ML"); a.max_splits = WM_ATTN_MAX_SPLITS;
     a.unit_flags = B<int>(h, "ATT_FLAGS");
+    const size_t hint_n = wm_attention_max_blocks((int)d.Mx, d.P < d.Td ? d.P : d.Td, d.heads);
+    const int site = c.attn_site++;
+    int* const hint0 = B<int>(h, "ATT_HINT") + (size_t)site * 3 * hint_n;
+    int* const stat0 = B<int>(h, "ATT_STAT") + (size_t)site * 3;
+    a.unit_hint = hint0; a.unit_stat = stat0;
+    bool general_only = false;
+    if (site * 3 < h->att_stat_n) {
+      // host policy from the (asynchronously mirrored, possibly one or two forwards old) counter: a quarter of the site's fast-kernel
+      // units on the general kernel since the last look -> general kernel only for the next WM_ATTN_HINT_TTL calls
+      const int cur = h->att_stat_host[site * 3], delta = cur - h->att_seen[site * 3];
+      h->att_seen[site * 3] = cur;
+      const long units = (long)((seq_len + 511) / 512) * (M / (seq_len > 0 ? seq_len : 1)) * heads;
+      if (delta > 0 && (long)delta * 4 >= units) h->att_general_ttl[site * 3] = WM_ATTN_HINT_TTL;
+      if (h->att_general_ttl[site * 3] > 0) { --h->att_general_ttl[site * 3]; general_only = true; }
+    }
     const bool sharded = is_global && (d.world > 1 || (force_gather && h->comm.kind != 0));
     const int ntpc = (M + 63) / 64;  // key tiles per rank chunk
     const bool overlap = wm_tuning[WM_TUNE_COMM_OVERLAP] >= 0 ? wm_tuning[WM_TUNE_COMM_OVERLAP] != 0 : overlap_env;
@@ -850,16 +891,18 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
       LCHK(c, hipEventRecord(h->cfork, c.s));
       // slice counts: minimise rounds x tiles per block over the resident slots, per launch (uniform slices only)
       static const int ncu = [] { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }();
-      // (unit size and residency of the kernel these launches take: 256-row units at two blocks per CU, or attn_v4's 512-row
-      //  units at one — f16)
-      int unit_rows = 256, per_cu = 2;
-      {
+      // Slice count of one piecewise launch over `ntiles` key tiles: the unit size and residency are those of the kernel THAT launch
+      // takes (with one view per rank the local launch is a 256-row-unit kernel and the remote ones attn_v4 with 512-row units at
+      // one block per CU), so each launch asks wm_attention_geometry with its own arguments
+      auto pick = [&](int chunks, int smax) {
         WmAttnArgs g = a;
-        g.force_partial = 1; g.seq_len = M; g.kv_chunks = 1;
+        g.force_partial = 1; g.seq_len = M; g.kv_head_stride = M;
+        if (chunks <= 1) { g.K = K16; g.V = V16; g.kv_chunks = 1; }
+        else { g.K = B<char>(h, "KVG"); g.V = g.K; g.kv_chunks = chunks; g.kv_rows_per_chunk = M; g.kv_chunk_stride = (long long)(2 * hsz / 2); }
+        int unit_rows = 256, per_cu = 2;
         wm_attention_geometry(g, &unit_rows, &per_cu);
-      }
-      const long slots = (long)per_cu * ncu, units = (long)((M + unit_rows - 1) / unit_rows) * heads;
-      auto pick = [&](int ntiles, int smax) {
+        const int ntiles = (chunks < 1 ? 1 : chunks) * ntpc;
+        const long slots = (long)per_cu * ncu, units = (long)((M + unit_rows - 1) / unit_rows) * heads;
         int best = 1; long best_cost = -1;
         for (int S = 1; S <= smax && S * 8 <= ntiles; ++S) {
           const long cost = ((units * S + slots - 1) / slots) * ((ntiles + S - 1) / S) + 6L * S;  // + partial write / read per slice
@@ -868,8 +911,8 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
         return best;
       };
       const int nb = rank, nc = world - 1 - rank;  // remote chunks before / after the own one
-      const int sa = pick(ntpc, 2);
-      const int sb = nb > 0 ? pick(nb * ntpc, nc > 0 ? 3 : 6) : 0, sc = nc > 0 ? pick(nc * ntpc, WM_ATTN_MAX_SPLITS - sa - sb) : 0;
+      const int sa = pick(1, 2);
+      const int sb = nb > 0 ? pick(nb, nc > 0 ? 3 : 6) : 0, sc = nc > 0 ? pick(nc, WM_ATTN_MAX_SPLITS - sa - sb) : 0;
       a.force_partial = 1;
       // (1) local keys, while the gather is in flight
       a.K = K16; a.V = V16; a.seq_len = M; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
@@ -887,12 +930,12 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
       ProfScope ps(h, 0, c.s);
       a.seq_len = M; a.kv_head_stride = M; a.kv_chunk_stride = (long long)(2 * hsz / 2); a.kv_rows_per_chunk = M;
       if (nb > 0) {
-        a.K = KVG; a.V = KVG + hsz; a.kv_chunks = nb; a.kv_splits = sb; a.part_slot0 = sa;
+        a.K = KVG; a.V = KVG + hsz; a.kv_chunks = nb; a.kv_splits = sb; a.part_slot0 = sa; a.unit_hint = hint0 + hint_n; a.unit_stat = stat0 + 1;
         LCHK(c, wm_launch_attention(a, c.s));
       }
       if (nc > 0) {
         char* base = KVG + (size_t)(rank + 1) * 2 * hsz;
-        a.K = base; a.V = base + hsz; a.kv_chunks = nc; a.kv_splits = sc; a.part_slot0 = sa + sb;
+        a.K = base; a.V = base + hsz; a.kv_chunks = nc; a.kv_splits = sc; a.part_slot0 = sa + sb; a.unit_hint = hint0 + 2 * hint_n; a.unit_stat = stat0 + 2;
         LCHK(c, wm_launch_attention(a, c.s));
       }
       LCHK(c, wm_launch_attention_combine(a, sa + sb + sc, c.s));
@@ -907,6 +950,7 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
       } else {
         a.K = K16; a.V = V16; a.seq_len = seq_len; a.kv_head_stride = M; a.kv_chunks = 1; a.kv_chunk_stride = 0; a.kv_rows_per_chunk = 0;
       }
+      if (general_only) { a.unit_flags = nullptr; a.unit_hint = nullptr; a.unit_stat = nullptr; }
       ProfScope ps(h, is_global ? 0 : 1, c.s);
       LCHK(c, wm_launch_attention(a, c.s));
     }
@@ -1007,7 +1051,7 @@ wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, cons
   a.Ho = (Hi + 2 * pad - ks) / stride + 1; a.Wo = (Wi + 2 * pad - ks) / stride + 1;
   a.relu_in = relu_in; a.resid_relu = resid_relu; a.relu_out = relu_out ? 1 : 0; a.in16 = in16 ? 1 : 0; a.dtype = c.hdt;
   if (out16) {  // the caller can take y as a 16-bit tensor (its only consumer rounds it to the operand type anyway): granted when the kernel can
-    static const int o16_env = [] { const char* e = getenv("WM_OUTCONV_GEMM"); return e ? atoi(e) : 1; }();
+    static const int o16_env = [] { const char* e = wm_env("WM_OUTCONV_GEMM"); return e ? atoi(e) : 1; }();
     *out16 = o16_env != 0 && wm_conv3x3_out16_ok(a);
     a.out16 = *out16 ? 1 : 0;
   }
@@ -1026,7 +1070,7 @@ wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, cons
 // writes exactly that — relu(conv1) as a 16-bit tensor — and conv2 stages it unconverted (bit-identical values; a quarter of the
 // bytes written, a quarter read: 268 MB less traffic per RCU at 148^2 x 8 views).  WM_RCU_MID16=0: the fp32 intermediate (A/B).
 wm_status rcu(Ctx& c, const std::string& p, const float* x, const float* extra, float* tmp, float* y, int N, int Hh, int Ww, bool* y16 = nullptr) {
-  static const bool mid16_env = [] { const char* e = getenv("WM_RCU_MID16"); return !e || atoi(e) != 0; }();
+  static const bool mid16_env = [] { const char* e = wm_env("WM_RCU_MID16"); return !e || atoi(e) != 0; }();
   const bool want = wm_tuning[WM_TUNE_RCU_MID16] >= 0 ? wm_tuning[WM_TUNE_RCU_MID16] != 0 : mid16_env;
   bool mid16 = false;
   wm_status st = conv(c, x, p + "conv1", true, nullptr, false, nullptr, tmp, N, Hh, Ww, 3, 1, 1, true, 0, 0, nullptr, nullptr, want ? &mid16 : nullptr, want);
@@ -1108,7 +1152,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     LCHK(c, wm_launch_bilinear(S0, S2, n, Hs[3], Ws[3], Hs[2], Ws[2], F_, nullptr, nullptr, c.s));
     float* cur = S2;  // output of the previous fusion block at level L
     // the two big resizes feed only a 3x3 conv: fuse them into that conv's input staging when the halo kernel applies
-    const bool fuse_on = wm_tuning[WM_TUNE_CONV_FUSE_UP] != 0 && getenv("WM_CONV_GENERIC") == nullptr;
+    const bool fuse_on = wm_tuning[WM_TUNE_CONV_FUSE_UP] != 0 && wm_env("WM_CONV_GENERIC") == nullptr;
     const bool fuse_up1 = fuse_on && F_ % 64 == 0 && 4 * Hs[0] * Ws[0] >= 256;
     const bool fuse_up2 = fuse_on && !is_gs && (F_ / 2) % 64 == 0;
     for (int L = 2; L >= 0; --L) {  // refinenet3 (level 2), refinenet2 (level 1), refinenet1 (level 0)
@@ -1145,7 +1189,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     // output_conv2[0] un-fused (measured: 16-bit LDS-tiled resize 260 us + DMA-fed 32-channel conv 255 us vs 600-630 us for the
     // fused-resize kernel at 8 views, tools/bench_up_conv_n32.py): resize into `fused` as 16-bit, conv reads it by LDS-DMA
     bool tail_done = false;
-    static const int up2_env = [] { const char* e = getenv("WM_UP2_UNFUSED"); return e ? atoi(e) : 1; }();
+    static const int up2_env = [] { const char* e = wm_env("WM_UP2_UNFUSED"); return e ? atoi(e) : 1; }();
     const Weight* w_oc2 = W(h, sc + "output_conv2.0.weight");
     const bool up2_unfused = up2_env && !is_gs && (F_ / 2) % 64 == 0 && F_ / 2 <= 128 && w_oc2 && w_oc2->shape[0] == 32 && w_oc2->w16 != nullptr;
     if (up2_unfused) {
@@ -1291,6 +1335,9 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
     }
   }
 
+  // fallback statistics of the fast attention kernels -> pinned host mirror (read by the NEXT forwards' launch policy; no synchronisation)
+  if (h->att_stat_host) LCHK(c, hipMemcpyAsync(h->att_stat_host, B<int>(h, "ATT_STAT"), (size_t)h->att_stat_n * 4, hipMemcpyDeviceToHost, s));
+
   // The camera head and the DPT heads are independent of each other: each runs on one of the handle's own queues, forked from and
   // joined back to the caller's stream (-1.15 ms per forward at 8 x 518^2, -5 ms at 32 views: the HBM-bound camera head and the under-filled small DPT
   // levels run beside the MFMA-bound convs).  WM_HEADS_CONCURRENT=0 (tuning heads_concurrent = 0) keeps one queue.
@@ -1302,7 +1349,7 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
   // WM_NO_PACKED_FP32 in wm_common.h; held by tests/test_kernel_resources_cpu.py, which disassembles every object), and those
   // GELU GEMMs of the backbone have finished before this fork.  tools/stress_concurrent_heads.py: 4 900 concurrent forwards (C2, C3, C5 flag set) bit-identical
   // to the serial one.
-  static const bool conc_env = [] { const char* e = getenv("WM_HEADS_CONCURRENT"); return !e || atoi(e) != 0; }();
+  static const bool conc_env = [] { const char* e = wm_env("WM_HEADS_CONCURRENT"); return !e || atoi(e) != 0; }();
   const bool serial = !(wm_tuning[WM_TUNE_HEADS_CONC] >= 0 ? wm_tuning[WM_TUNE_HEADS_CONC] != 0 : conc_env) || h->prof;
   if (!h->hfork) LCHK(c, hipEventCreateWithFlags(&h->hfork, hipEventDisableTiming));
   if (!serial) LCHK(c, hipEventRecord(h->hfork, s));
@@ -1515,6 +1562,36 @@ extern "C" wm_status wm_op_attention_ex(int dtype, const void* Q, const void* K,
   a.Q = Q; a.K = K; a.V = V; a.O = O; a.H = H; a.q_rows = q_rows; a.seq_len = seq_len; a.q_head_stride = q_rows;
   a.kv_chunks = kv_chunks; a.dtype = dtype; a.kv_splits = kv_splits; a.max_splits = WM_ATTN_MAX_SPLITS; a.part_o = part_o; a.part_ml = part_ml;
   a.unit_flags = unit_flags;
+  // the second half of the caller's flag buffer holds the sticky hints (wm_op_attention_flag_count counts both halves): a caller that
+  // reuses one zero-initialised buffer across calls gets the forward's behaviour, one that clears it per call the hint-free one
+  if (unit_flags) {
+    const size_t nb = wm_attention_max_blocks(q_rows, seq_len, H);
+    a.unit_hint = unit_flags + nb;
+    a.unit_stat = unit_flags + 2 * nb;
+    // the forward's host policy (backbone_block) for ONE buffer at a time, when the tuning key attn_op_policy is 1 (tools/bench_attn_v4.py)
+    const bool policy = wm_tuning[WM_TUNE_ATTN_OP_POLICY] == 1;
+    static int* mirror = nullptr;
+    static const int* key = nullptr;
+    static int seen = 0, ttl = 0;
+    if (!mirror && hipHostMalloc((void**)&mirror, 4, hipHostMallocDefault) != hipSuccess) return WM_ERR_HIP;
+    if (key != unit_flags) { key = unit_flags; seen = 0; ttl = 0; *mirror = 0; }
+    const int cur = *mirror, delta = cur - seen;
+    seen = cur;
+    const long units = (long)((seq_len + 511) / 512) * (q_rows / (seq_len > 0 ? seq_len : 1)) * H;
+    if (delta < 0) ttl = 0;                                   // the caller cleared its buffer
+    else if (delta > 0 && (long)delta * 4 >= units) ttl = WM_ATTN_HINT_TTL;
+    const bool general_only = policy && ttl > 0;
+    if (general_only) --ttl;
+    int* stat = a.unit_stat;
+    if (general_only) { a.unit_flags = nullptr; a.unit_hint = nullptr; a.unit_stat = nullptr; }
+    if (kv_chunks > 1) {
+      a.kv_head_stride = kv_rows_per_chunk; a.kv_rows_per_chunk = kv_rows_per_chunk; a.kv_chunk_stride = (long long)H * kv_rows_per_chunk * 64;
+    } else {
+      a.kv_head_stride = q_rows;
+    }
+    if (wm_launch_attention(a, (hipStream_t)stream) != hipSuccess) return WM_ERR_HIP;
+    return hipMemcpyAsync(mirror, stat, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+  }
   if (kv_chunks > 1) {
     a.kv_head_stride = kv_rows_per_chunk; a.kv_rows_per_chunk = kv_rows_per_chunk; a.kv_chunk_stride = (long long)H * kv_rows_per_chunk * 64;
   } else {
@@ -1522,7 +1599,8 @@ extern "C" wm_status wm_op_attention_ex(int dtype, const void* Q, const void* K,
   }
   return wm_launch_attention(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
-extern "C" size_t wm_op_attention_flag_count(int q_rows, int seq_len, int H) { return wm_attention_max_blocks(q_rows, seq_len, H); }
+// ints of the caller's buffer: [flags | sticky hints | 1 fallback counter (+ pad)]
+extern "C" size_t wm_op_attention_flag_count(int q_rows, int seq_len, int H) { return 2 * wm_attention_max_blocks(q_rows, seq_len, H) + 4; }
 // resize (align_corners bilinear + position tables) to 16 bits, then the 32-channel 3x3 conv on it: the unfused form of
 // wm_op_conv3x3_up for Cout == 32.  up16: Hi * Wi * N * Cin 16-bit elements + 16 B of scratch (zeroed here).
 extern "C" wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi,

@@ -31,6 +31,21 @@ def test_exports_match_header(L):
         assert hasattr(L, n), n
 
 
+def test_shipped_library_reads_no_wm_environment_switch(L):
+    """The product build must not be steerable from the environment (a WM_ATTN_DEBUG_SKIP in the shipped library could
+    return wrong results): every historical WM_* switch goes through wm_env(), which is compiled out without -DWM_DIAG_ENV, so no
+    such name may be left among the library's strings.  (getenv itself is still imported: rocPRIM's headers in raster / splat_prune.)"""
+    data = open(LIB, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"WM_[A-Z][A-Z0-9_]{3,}", data))
+    names -= {"WM_OK"}
+    envlike = sorted(n for n in names if not n.startswith(("WM_ERR", "WM_EPI", "WM_T_", "WM_ACT", "WM_TUNE", "WM_RCCL")))
+    assert not envlike, envlike
+    src = os.path.join(ROOT, "hunyuanworld-mirror_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".cpp")):
+            assert "getenv(" not in open(os.path.join(src, f)).read(), f
+
+
 def test_config_struct_layout_matches_header():
     from hunyuanworld_mirror_amd import _lib
     assert C.sizeof(_lib.wm_config) == 4 * (4 + 6 + 4 + 4 + 1 + 2 + 3 + 1 + 4 + 2)

@@ -120,7 +120,7 @@ def test_gemm_row_band_schedule_is_bit_identical(dev, M, N, K, cfg):
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 448, 1024, 4096])
 @pytest.mark.parametrize("cfg", [4, 5])
 def test_gemm_pingpong_v3_matches_v2_bitwise(dev, K, cfg):
-    """The half-the-barriers schedule (gemm_pp2_kernel VER = 3, the default) against the two-barriers-per-stage one (gemm_pp = 2):
+    """The half-the-barriers schedule (gemm_pp2_kernel VER = 3, tuning gemm_pp = 4) against the shipped two-barriers-per-stage one:
     same MFMAs in the same order, so any difference is a synchronisation fault (a fragment read before its LDS-DMA landed, or a
     region refilled while a wave still read it).  K from one K-tile up (the prologue / tail branches of the counted waits), both
     tile heights, odd row counts, several launches back to back."""
@@ -132,11 +132,11 @@ def test_gemm_pingpong_v3_matches_v2_bitwise(dev, K, cfg):
         W = _t16(torch.randn(N, K, generator=g) / math.sqrt(K), BF16).to(dev)
         bias = torch.randn(N, generator=g).to(dev)
         outs = {}
-        for ver in (2, -1):
+        for ver in (2, 4):
             assert L.wm_set_tuning(b"gemm_cfg", cfg) == 0 and L.wm_set_tuning(b"gemm_pp", ver) == 0
             try:
                 res = []
-                for rep in range(4 if ver == -1 else 1):
+                for rep in range(4 if ver == 4 else 1):
                     f32 = torch.empty(M, N, device=dev)
                     ge = torch.empty(M, N, device=dev, dtype=torch.int16)
                     assert L.wm_op_gemm(BF16, 0, _p(A), _p(W), _p(f32), _p(bias), None, M, N, K, s) == 0
@@ -148,7 +148,7 @@ def test_gemm_pingpong_v3_matches_v2_bitwise(dev, K, cfg):
                 L.wm_set_tuning(b"gemm_cfg", -1); L.wm_set_tuning(b"gemm_pp", -1)
         ref32, refge = outs[2][0]
         assert _rel(ref32, A.float() @ W.float().t() + bias) < 2e-5
-        for rep, (f32, ge) in enumerate(outs[-1]):
+        for rep, (f32, ge) in enumerate(outs[4]):
             assert torch.equal(f32, ref32), f"f32 differs: M={M} N={N} K={K} cfg={cfg} rep={rep}"
             assert torch.equal(ge, refge), f"gelu differs: M={M} N={N} K={K} cfg={cfg} rep={rep}"
 
@@ -418,7 +418,7 @@ def _run_attn_ex(L_, q, k, v, H, R, Ls, chunks, Lc, splits, qb, dev, dt=BF16):
         torch.cuda.synchronize()
     finally:
         L_.wm_set_tuning(b"attn_qb", -1)
-    return _from16(o, dt).reshape(R, H, 64), flags
+    return _from16(o, dt).reshape(R, H, 64), flags[: (flags.numel() - 4) // 2]   # ([flags | sticky hints | counter])
 
 
 @pytest.mark.parametrize("H,nseq,L,chunks,splits", [(4, 1, 2752, 1, 1), (16, 1, 11008, 1, 0), (3, 2, 1408, 1, 1), (4, 1, 2816, 2, 2), (2, 1, 4096, 4, 0),
@@ -583,6 +583,59 @@ def test_attention_v4_out_of_range_rows_are_recomputed(dev, dt, kind):
     print(f"v4 {kind} dt{dt}: flags {used.tolist()}")
     if not (dt == F16 and kind == "all_far_below_zero"):   # (f16 subtracts a max: uniformly low scores are in range there)
         assert 1 <= nflag <= 2 * len(expect) + 2, used.tolist()
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("where", ["first_tile", "late"])
+def test_attention_sink_shaped_scores_and_sticky_hint(dev, dt, where):
+    """Attention-sink logits (a few keys far above the rest for EVERY query, as register / camera tokens of a trained ViT produce):
+    in the first key tile the fast kernels must take them in their stride (bf16: 2^S stays far inside fp32; f16: the fixed row max
+    comes from that tile); arriving late and beyond the fast range (bf16: 2^130 overflows the row sum; f16: 2^50 above the window
+    set after 64 keys) every unit is flagged and recomputed — and REMEMBERED: on the following calls the unit's hint sends it to
+    the general kernel alone (flag 17 = by hint), counting down WM_ATTN_HINT_TTL until the fast kernel is tried again.  Results
+    against the fp32 softmax on every call."""
+    L_ = _lib()
+    H, L = 4, 4096
+    g = torch.Generator().manual_seed(11 + dt)
+    u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+    q = torch.randn(H, L, 64, generator=g) * 0.125 * 1.5 * LOG2E + 2.0 * u
+    k = torch.randn(H, L, 64, generator=g) * 1.5
+    v = torch.randn(H, L, 64, generator=g)
+    gain = (65.0 if dt == BF16 else 25.0) if where == "late" else (30.0 if dt == BF16 else 20.0)   # score = gain * (2 + noise) log2 units
+    pos = [3000, 3001, 3002, 4090] if where == "late" else [0, 5, 17, 40]
+    for h in range(H):
+        for j, ps in enumerate(pos): k[h, ps] = u * gain * (1.0 - 0.03 * j)
+    q, k, v = [_t16(x, dt).to(dev) for x in (q, k, v)]
+    ref = _attn_ref(q.float(), k.float(), v.float()).transpose(0, 1)
+    o = torch.zeros(L, H * 64, device=dev, dtype=torch.int16)
+    po = torch.zeros((8, L, H * 64), device=dev); pml = torch.zeros((8, H, L, 2), device=dev)
+    ntot = int(L_.wm_op_attention_flag_count(L, L, H))
+    n = ntot - 4                                               # [flags | hints | counter + pad]
+    buf = torch.zeros((ntot,), device=dev, dtype=torch.int32)  # kept across the calls like the forward's workspace
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L_.wm_set_tuning(b"attn_qb", 8) == 0
+    try:
+        seen = []
+        for call in range(4):
+            buf[: n // 2] = -1
+            o.zero_()
+            assert L_.wm_op_attention_ex(dt, _p(q), _p(k), _p(v), _p(o), H, L, L, 1, 0, 1, _p(po), _p(pml), _p(buf), s) == 0
+            torch.cuda.synchronize()
+            got = _from16(o, dt).reshape(L, H, 64)
+            e = _rel(got, ref)
+            flags = buf[: n // 2]; used = flags[flags >= 0]; hints = buf[n // 2: n]
+            seen.append((sorted(set(used.tolist())), int(hints.max())))
+            print(f"sink {where} dt{dt} call {call}: rel-L2 {e:.2e}, flag values {seen[-1][0]}, max hint {seen[-1][1]}")
+            assert torch.isfinite(got).all() and e < (1e-2 if dt == BF16 else 2e-3)
+            assert used.numel() == H * (L // 512)
+        if where == "first_tile":
+            assert all(f == [0] and hmax == 0 for f, hmax in seen), "sinks inside the first key tile must stay on the fast kernel"
+        else:
+            assert 0 not in seen[0][0] and 17 not in seen[0][0] and seen[0][1] == 15      # every unit flagged by the computation, remembered
+            for call in (1, 2, 3):
+                assert seen[call][0] == [17] and seen[call][1] == 15 - call               # by hint only, counting down
+    finally:
+        L_.wm_set_tuning(b"attn_qb", -1)
 
 
 @pytest.mark.parametrize("D", [128, 256, 1024, 2048])

@@ -96,9 +96,9 @@ def test_two_virtual_ranks_long_sequences_use_split_kv():
 
 
 def test_rccl_allgather_path_single_rank():
-    """The RCCL collective itself (ncclAllGather on the handle's own communicator) at world size 1:
-    WM_FORCE_GATHER routes global attention through the gathered-K/V path.  Run in a subprocess because
-    the switch is read once per process."""
+    """The RCCL collective itself (ncclAllGather on the handle's own communicator) at world size 1: the tuning key
+    force_gather routes global attention through the gathered-K/V path (the shipped library reads no environment
+    switch).  Run in a subprocess so that the RCCL communicator lives and dies with it."""
     import os, subprocess, sys
     code = r"""
 import sys, ctypes as C, torch
@@ -111,13 +111,14 @@ L = _lib.lib()
 ident = (C.c_uint8 * 128)()
 assert L.wm_rccl_unique_id(ident) == 0
 assert L.wm_comm_init_rccl(m._handle, ident, 0, 1) == 0, m._err()
+assert L.wm_set_tuning(b"force_gather", 1) == 0
 out = m({k: torch.from_numpy(v).cuda() for k, v in views.items()}, flags)
 torch.cuda.synchronize()
 e = rel_l2(out['pts3d'].cpu().numpy(), outs['pts3d'])
 print('rccl world-1 pts3d', e)
 assert e < 5e-3
 """
-    env = dict(os.environ, WM_FORCE_GATHER="1")
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     print(r.stdout[-500:], r.stderr[-1500:])
     assert r.returncode == 0

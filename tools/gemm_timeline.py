@@ -87,7 +87,7 @@ if mode == "sched":
         for name, epi, N, K in SHAPES:
             A, W, bias, gamma = operands(M, N, K)
             f = runner(M, N, K, epi, A, W, bias, gamma)
-            arms = (("v2_full_height", 2, 0), ("v2_scheduled", 2, -1), ("v3_full_height", -1, 0), ("v3_scheduled", -1, -1))
+            arms = (("v2_full_height", 2, 0), ("v2_scheduled", 2, -1), ("v3_full_height", 4, 0), ("v3_scheduled", 4, -1))
             res = {k: [] for k, _, _ in arms}
             heat(f, 0.5)
             for _ in range(7):
@@ -104,7 +104,7 @@ elif mode == "exp":
             A, W, bias, gamma = operands(M, N, K)
             f = runner(M, N, K, 0, A, W, bias, gamma)
             for cfg, rows in ((4, 256), (5, 192)):
-                for pp, label in ((2, "v2"), (1, "v3_shipped"), (17, "v2_same_rows_all_l2_hits"), (101, "v2_no_dma"), (102, "v2_no_frag_reads"), (104, "v2_no_barriers"), (108, "v2_no_setprio"),
+                for pp, label in ((2, "v2_shipped"), (4, "v3_half_the_barriers"), (17, "v2_same_rows_all_l2_hits"), (101, "v2_no_dma"), (102, "v2_no_frag_reads"), (104, "v2_no_barriers"), (108, "v2_no_setprio"),
                                   (103, "v2_no_dma_no_reads"), (105, "v2_no_dma_no_barriers"), (112, "v2_no_barriers_no_setprio"), (107, "v2_no_dma_reads_barriers"), (115, "v2_mfma_only")):
                     assert L.wm_set_tuning(b"gemm_cfg", cfg) == 0 and L.wm_set_tuning(b"gemm_pp", pp) == 0 and L.wm_set_tuning(b"gemm_sched", 0) == 0
                     heat(f, 0.7)
