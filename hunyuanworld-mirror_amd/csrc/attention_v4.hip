@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
                                                       // keeps one pair in a 64-bit register and pads a wait state in front of every statement using it)
   f32x16 cinit[QB];      // f16: -m broadcast (the QK chain's initial accumulator)
   float m_run[QB];
+  float s_run[QB];   // f16: sum of the first tile's scores per row (its mean places the fixed row max when the tile holds a sink)
 #pragma unroll
   for (int b = 0; b < QB; ++b) {
     lsum[b][0] = lsum[b][1] = lsum[b][2] = lsum[b][3] = 0.f;
@@ -515,15 +516,21 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
       asm volatile("s_nop 15\n\ts_nop 7" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]));
 #pragma unroll
       for (int b = 0; b < QB; ++b) {
-        float mx = st[b][0];
+        float mx = st[b][0], sm = st[b][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[b][r]);
+        for (int r = 1; r < 16; ++r) { mx = fmaxf(mx, st[b][r]); sm += st[b][r]; }
         m_run[b] = hf == 0 ? mx : fmaxf(m_run[b], mx);
+        s_run[b] = hf == 0 ? sm : s_run[b] + sm;
       }
     }
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-      m_run[b] = ceilf(xhalf_max(m_run[b])) + F16_HEADROOM;
+      // m = max0 + headroom, unless the first tile shows a SINK (its maximum far above its mean): then the bulk of the row's keys sits
+      // far below max0 and max0 + 4 would push their P = 2^(S - m) below f16's normal range (flushed in O, still counted in the fp32
+      // row sum: with 44 K keys 18 log2 units under a sink that loses ~8 % of the row's mass from O — ADVICE r03).  m = mean0 + 14 puts
+      // the bulk at 2^-14 and the sink at 2^(gap - 14); never below max0 - 12 (the first tile's own maximum must stay < 2^16).
+      const float mx0 = xhalf_max(m_run[b]), mean0 = xhalf_sum(s_run[b]) * (1.0f / 64.0f);
+      m_run[b] = ceilf(fmaxf(fminf(mx0 + F16_HEADROOM, mean0 + 14.0f), mx0 - 12.0f));
 #pragma unroll
       for (int r = 0; r < 16; ++r) cinit[b][r] = -m_run[b];
     }
@@ -562,9 +569,13 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
       __builtin_amdgcn_sched_barrier(0);
       step(PC_FULL{}, slot_c, 0, std::integral_constant<int, (WM_V4_DIAG & 4) ? 0 : 1>{});
     } else {
+      // lgkmcnt(0): the V^T fragment reads of step 2j-1 (consumed only in step 2j) must have LEFT the ring slot before another wave's
+      // DMA of tile j+2 may land in it — they are ~6 MFMA gaps old here, so the wait is free; it states what the timing implied
       if constexpr (!(WM_V4_DIAG & 8)) {
-        if (j + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (j + 1 < nt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       if constexpr (!(WM_V4_DIAG & 1)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -612,7 +623,10 @@ __global__ __launch_bounds__(256, 1) void attn_v4_kernel(const WmAttnArgs p, int
     if (npad) {   // take the zero keys' P (2^(0 - m) each, the same v_exp_f32 the loop evaluated) out of the sum again
       const float pads = (float)npad * (F16 ? __builtin_amdgcn_exp2f(-m_run[b]) : 1.0f);
       l[b] -= pads;
-      bad |= !(l[b] >= pads * 2.44140625e-4f) ? 8 : 0;   // 2^-12: below that the fp32 sum has lost the true part against the pads
+      // the true sum must not be lost against the pads': fp32 keeps it to 2^-24 of the pads' sum, so at a ratio of 2^-12 (bf16: 8 significant
+      // bits out, 2^-12 relative is plenty) or 2^-8 (f16: 11 bits out — at 2^-12 the normaliser's cancellation error would be one f16 ulp
+      // on every output of the row) the result is still right; below it the general kernel recomputes the unit
+      bad |= !(l[b] >= pads * (F16 ? 3.90625e-3f : 2.44140625e-4f)) ? 8 : 0;
     }
     if constexpr (F16) {
       float t = 0.f;   // stays 0 iff every O value of the row is finite (x * 0 is NaN for inf and NaN)

@@ -585,6 +585,45 @@ def test_attention_v4_out_of_range_rows_are_recomputed(dev, dt, kind):
         assert 1 <= nflag <= 2 * len(expect) + 2, used.tolist()
 
 
+@pytest.mark.parametrize("qb", [8, 3])
+@pytest.mark.parametrize("kind", ["sink_in_first_tile_bulk_18_below", "wide_gaussian_sigma_7", "uniformly_low_ragged_1376"])
+def test_attention_f16_wide_score_spread(dev, qb, kind):
+    """f16 P = 2^(S - m) has 5 exponent bits: with m fixed from the first key tile (attn_v4) the keys far below it lose bits or flush in
+    O while the fp32 row sum still counts them.  Three distributions with a NON-ZERO mean in V (so lost mass shows):
+    a sink in the first tile 18 log2 units above 22 K bulk keys (8 % of the row's mass sits in the bulk), gaussian scores with a
+    sigma of 7 log2 units, and per-frame 1376-key rows (32 zero pads in the ragged last tile) whose scores all sit 10 - 14 log2
+    units below zero.  fp32 softmax at the f16 tolerance; the general kernel (3) is held to the same bound."""
+    L_ = _lib()
+    H = 2
+    g = torch.Generator().manual_seed(29)
+    u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+    if kind == "sink_in_first_tile_bulk_18_below":
+        L, nseq = 16 * 1376, 1
+        q = torch.randn(H, L, 64, generator=g) * 0.125 * 1.2 * LOG2E + 1.0 * u
+        k = torch.randn(H, L, 64, generator=g) * 1.2
+        k[:, 3] = u * 18.0
+    elif kind == "wide_gaussian_sigma_7":
+        L, nseq = 8 * 1376, 1
+        q = torch.randn(H, L, 64, generator=g) * 0.5
+        k = torch.randn(H, L, 64, generator=g) * 1.75     # q.k ~ N(0, 64 * 0.5^2 * 1.75^2) = N(0, 7^2) in log2 units
+    else:
+        L, nseq = 1376, 4
+        q = torch.randn(H, L * nseq, 64, generator=g) * 0.02 + 1.0 * u
+        k = torch.randn(H, L * nseq, 64, generator=g) * 0.5 - 12.0 * u
+    R = L * nseq
+    v = torch.randn(H, R, 64, generator=g) + 1.0
+    q, k, v = [_t16(x, F16).to(dev) for x in (q, k, v)]
+    got, flags = _run_attn_ex(L_, q, k, v, H, R, L, 1, 0, 1, qb, dev, F16)
+    errs = []
+    for i in range(nseq):
+        sl = slice(i * L, (i + 1) * L)
+        ref = _attn_ref(q[:, sl].float(), k[:, sl].float(), v[:, sl].float()).transpose(0, 1)
+        errs.append(_rel(got[sl], ref))
+    nflag = int((flags[flags >= 0] != 0).sum()) if qb == 8 else 0
+    print(f"f16 {kind} qb{qb}: rel-L2 {max(errs):.2e}, flagged units {nflag}")
+    assert torch.isfinite(got).all() and max(errs) < 2e-3
+
+
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("where", ["first_tile", "late"])
 def test_attention_sink_shaped_scores_and_sticky_hint(dev, dt, where):
