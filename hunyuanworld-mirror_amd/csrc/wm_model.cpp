@@ -440,7 +440,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -749,6 +749,22 @@ wm_status comm_allgather(wm_handle* h, const void* send, void* recv, size_t byte
   ProfScope ps(h, 12, s);   // timing kind 12: the collective, on the queue it runs on (the compute queue unless WM_COMM_OVERLAP=1)
   Comm& cm = h->comm;
   if (cm.kind == 1) {
+    if (wm_tuning[WM_TUNE_COMM_P2P] == 1 && cm.world > 1) {
+      // Direct all-gather (opt-in, tuning comm_p2p = 1 / bench.py --gather p2p): every rank sends its chunk to every peer and
+      // receives every peer's chunk as ONE group of point-to-point operations, so each of the 7 xGMI links of a GPU carries one
+      // chunk in each direction at once (~0.29 ms per layer link-bound at C4, against ~2.1 ms if the all-gather
+      // runs as a ring).  Not the default: no multi-GPU node was available to any build round, and RCCL may already pick a
+      // direct algorithm for ncclAllGather on a fully connected node — the first 8-GPU run has to say.
+      if (ncclGroupStart() != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclGroupStart failed");
+      for (int r = 0; r < cm.world; ++r) {
+        if (r == cm.rank) continue;
+        if (ncclSend(send, bytes, ncclInt8, r, cm.nccl, s) != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclSend failed");
+        if (ncclRecv((char*)recv + (size_t)r * bytes, bytes, ncclInt8, r, cm.nccl, s) != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclRecv failed");
+      }
+      if (ncclGroupEnd() != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclGroupEnd failed");
+      HIPCHK(h, hipMemcpyAsync((char*)recv + (size_t)cm.rank * bytes, send, bytes, hipMemcpyDeviceToDevice, s));
+      return WM_OK;
+    }
     if (ncclAllGather(send, recv, bytes, ncclInt8, cm.nccl, s) != ncclSuccess) return fail(h, WM_ERR_COMM, "ncclAllGather failed");
     return WM_OK;
   }

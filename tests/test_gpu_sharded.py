@@ -95,6 +95,81 @@ def test_two_virtual_ranks_long_sequences_use_split_kv():
     L.wm_local_group_destroy(grp)
 
 
+def test_bench_two_pass_gather_decision_with_virtual_ranks():
+    """bench.py's N > 1 path: time the serial gather and the overlapped gather, compare one forward of each
+    on every rank, headline the faster one only if the comparison passed.  Here the same function (bench.two_pass_overlap) runs on
+    two in-process ranks of one GPU (host threads; reductions through a barrier instead of torch.distributed): both modes must
+    execute (the 3-view x 791-token chunks are long enough for the overlapped form), agree within the key-partition-order floor,
+    and the function must leave the tuning at its choice."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from hunyuanworld_mirror_amd import WorldMirror, WMConfig, _lib
+    cfg = WMConfig.tiny()
+    g = torch.Generator().manual_seed(7)
+    tv = {"img": torch.rand(1, 6, 3, 392, 392, generator=g).cuda()}
+    L = _lib.lib()
+    world = 2
+    grp = C.c_void_p(L.wm_local_group_create(world))
+    models = [WorldMirror(arch=cfg).init_synthetic_weights().to("cuda:0").shard_local(grp, r, world) for r in range(world)]
+    bar = threading.Barrier(world)
+    box, infos, errs = [0.0] * world, [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+
+            def allmax(x):
+                box[r] = float(x)
+                bar.wait(120)
+                v = max(box)
+                bar.wait(120)
+                return v
+
+            def set_overlap(v):   # the tuning is process-wide: nobody may still be inside a forward of the other mode
+                bar.wait(120)
+                if r == 0:
+                    assert L.wm_set_tuning(b"comm_overlap", v) == 0
+                bar.wait(120)
+
+            def fwd():
+                o = models[r](tv)
+                torch.cuda.synchronize()
+                return o
+
+            def timed():
+                import time
+                bar.wait(120)
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    models[r](tv)
+                torch.cuda.synchronize()
+                bar.wait(120)
+                return (time.perf_counter() - t0) / 2 * 1e3
+            infos[r] = bench.two_pass_overlap(set_overlap, fwd, timed, allmax)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    try:
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        assert not errs, errs
+        assert all(not t.is_alive() for t in th), "two-pass bench path deadlocked"
+        pick, ms, info = infos[0]
+        print(info)
+        assert infos[1][0] == pick and info["comparison_passed"], info
+        assert info["max_rel_l2_between_modes_over_ranks"] < info["bound"]
+        assert set(info["ms_per_step"]) == {"comm_overlap_0", "comm_overlap_1"} and abs(ms - info["ms_per_step"][f"comm_overlap_{pick}"]) < 1e-3
+    finally:
+        L.wm_set_tuning(b"comm_overlap", -1)
+        del models
+        L.wm_local_group_destroy(grp)
+
+
 def test_rccl_allgather_path_single_rank():
     """The RCCL collective itself (ncclAllGather on the handle's own communicator) at world size 1: the tuning key
     force_gather routes global attention through the gathered-K/V path (the shipped library reads no environment
