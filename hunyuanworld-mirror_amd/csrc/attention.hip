@@ -340,22 +340,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
     return;
   }
 
-  // ---- epilogue: O[q][head*64 + d] = O^T / l
+  // ---- epilogue: O[q][head*64 + d] = O^T / l.  A lane holds 4-column pieces of its row (columns 32d + 8g + 4h ..+3); v_permlane32_swap
+  // pairs the pieces g and g+1 of the two lane halves into 8 consecutive columns: 16-B stores instead of 8-B ones (guides T21; the
+  // fast kernels' epilogues do the same).  Every lane takes part in the swaps; only the stores are masked.
 #pragma unroll
   for (int b = 0; b < QB; ++b) {
     const float inv = 1.0f / xhalf_sum(l_run[b]);
-    if (q_valid[b]) {
-      u16* op = (u16*)p.O + ((size_t)(seq_row0 + qrow[b]) * p.H + head) * 64;
+    u16* op = (u16*)p.O + ((size_t)(seq_row0 + (q_valid[b] ? qrow[b] : 0)) * p.H + head) * 64;
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 u;
-          u.x = pack2(ot[b][d][4 * g + 0] * inv, ot[b][d][4 * g + 1] * inv, T);
-          u.y = pack2(ot[b][d][4 * g + 2] * inv, ot[b][d][4 * g + 3] * inv, T);
-          *(uint2*)(op + 32 * d + 8 * g + 4 * h) = u;
-        }
-    }
+      for (int g = 0; g < 4; g += 2) {
+        uint32_t a0 = pack2(ot[b][d][4 * g + 0] * inv, ot[b][d][4 * g + 1] * inv, T);
+        uint32_t a1 = pack2(ot[b][d][4 * g + 2] * inv, ot[b][d][4 * g + 3] * inv, T);
+        uint32_t b0 = pack2(ot[b][d][4 * g + 4] * inv, ot[b][d][4 * g + 5] * inv, T);
+        uint32_t b1 = pack2(ot[b][d][4 * g + 6] * inv, ot[b][d][4 * g + 7] * inv, T);
+        // swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b.  After: h = 0 {a, b} = columns 8g..8g+7, h = 1 {a, b} = 8g+8..8g+15
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+        if (q_valid[b]) *(uint4*)(op + 32 * d + 8 * g + 8 * h) = make_uint4(a0, a1, b0, b1);
+      }
   }
 }
 
