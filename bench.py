@@ -347,7 +347,7 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # value is the committed rocprofv3 --pmc measurement of THIS workload (profiles/r01_traffic_n1.json), else null
         traffic = None
-        tpath = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic_n1.json", "r02_traffic_n1.json", "r01_traffic_n1.json")) if os.path.exists(p)), "")
+        tpath = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r04_traffic_n1.json", "r03_traffic_n1.json", "r02_traffic_n1.json", "r01_traffic_n1.json")) if os.path.exists(p)), "")
         if world == 1 and n_local == 8 and H == 518 and not a.tiny and tpath:
             traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
