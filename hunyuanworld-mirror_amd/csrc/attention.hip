@@ -366,7 +366,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_fwd_kernel(const WmAttnArg
 // ---------------------------------------------------------------------------------------------------------
 // Software-pipelined variant for long sequences (cross-view attention).
 //
-// Measured on the kernel above (tools/attn_exp.py, 32 views): deleting the softmax VALU saves 18 %, deleting the K/V
+// Measured on the kernel above (tools/attn_exp.py (rounds 1-2; git history), 32 views): deleting the softmax VALU saves 18 %, deleting the K/V
 // streaming + barrier 19 %, three quarters of the MFMAs 35 %, and one wave per SIMD is only 1.46x slower than two:
 // a wave runs QK^T -> softmax -> PV strictly one after the other and its SIMD partner fills the gaps only by chance.
 // Here the tile is processed as two 32-key halves, staggered: every half-step is ONE basic block that holds

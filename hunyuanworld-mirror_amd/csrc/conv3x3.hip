@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void conv3x3_rs_kernel(const WmConvArgs p) {
   // float4 structs instead of native vectors, end up in scratch memory).  hipcc's waitcnt bookkeeping merges
   // conservatively across the loop back-edge, so the ds_writes at the end of a tap still wait for the newest loads
   // (fully unrolling 18 taps makes the waits exact but spills); even so this loop measures +8-22 % over the LDS-DMA
-  // one (tools/bench_conv.py): raw barrier, no vmcnt(0) drain at the top of the tap, no DMA issue.  Needs an even
+  // one (tools/bench_conv.py (rounds 1-2; git history)): raw barrier, no vmcnt(0) drain at the top of the tap, no DMA issue.  Needs an even
   // number of 64-channel chunks (the two-tap step walks chunk pairs).
   auto tap_body = [&](int cc, int tap, int PAR, WSet& w_mine, WSet& w_other, HItem& h_mine, HItem& h_other) {
     const int kt = cc * 9 + tap;
@@ -702,7 +702,7 @@ int pick_bn(const WmConvArgs& a) {  // output-channel tile (see launch_T)
 template <int T>
 hipError_t launch_T(const WmConvArgs& a, hipStream_t s) {
   // output-channel tile: as wide as Cout allows, but narrower while the launch would cover less than half the chip
-  // (the 19^2 and 37^2 DPT levels: 32 / 72 pixel tiles; measured with tools/bench_conv.py: 37^2 161 -> 249 TF/s at
+  // (the 19^2 and 37^2 DPT levels: 32 / 72 pixel tiles; measured with tools/bench_conv.py (rounds 1-2; git history): 37^2 161 -> 249 TF/s at
   // 128 channels, 19^2 46 -> 112 at 64; 74^2 with 200 tiles stays fastest at 256) — the halo is then re-staged per
   // channel tile, from L2.  conv_bn (tuning) forces a width.
   static const int ncu = cu_count();

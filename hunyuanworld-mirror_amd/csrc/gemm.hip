@@ -1190,7 +1190,7 @@ hipError_t launch_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
 template <int T>
 hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
   // 16x16x32 MFMA main loop: measured +3..8 % on the N=1024 GEMMs (proj, fc2) and +0..2 % on QKV, neutral/negative
-  // on fc1 (tools/bench_gemm.py); WM_GEMM_MFMA16 = 0 / 2 forces it off / on for every backbone epilogue
+  // on fc1 (tools/bench_gemm.py (rounds 1-2; git history)); WM_GEMM_MFMA16 = 0 / 2 forces it off / on for every backbone epilogue
   static const int mf16_env = [] { const char* e = wm_env("WM_GEMM_MFMA16"); return e ? atoi(e) : 1; }();
   static const int pp_env = [] { const char* e = wm_env("WM_GEMM_PP"); return e ? atoi(e) : 1; }();
   const int mf16 = wm_tuning[WM_TUNE_GEMM_MFMA16] >= 0 ? wm_tuning[WM_TUNE_GEMM_MFMA16] : mf16_env;
@@ -1253,7 +1253,7 @@ int pick_cfg(const WmGemmArgs& a) {
   // first-order loss at M = 11008 (e.g. 516 tiles of 256^2 on 256 CUs = 3 rounds)
   static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
   struct Cand { int id, bm, bn, per_cu; float eff; };
-  // relative tile efficiencies measured with tools/check_gemm_pp.py (cfg 4 = ping-pong v2, cfg 5 = ping-pong v1 at 192 x 256)
+  // relative tile efficiencies measured with tools/check_gemm_pp.py (rounds 1-2; git history) (cfg 4 = ping-pong v2, cfg 5 = ping-pong v1 at 192 x 256)
   static const Cand cands[] = {{4, 256, 256, 1, 1.00f}, {5, 192, 256, 1, 0.85f}, {1, 256, 128, 1, 0.70f}, {0, 128, 128, 2, 0.58f}};
   int best = 4;
   float best_cost = 1e30f;
