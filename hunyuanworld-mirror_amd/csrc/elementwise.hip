@@ -67,6 +67,64 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const WmLnArgs p) {
   }
 }
 
+// The backbone's case (D = NV * 256 exactly, affine, 16-bit output) without a branch and with every load of the row's life — x, weight
+// and bias — requested up front.  The general kernel above tests `c < D` per chunk, so hipcc emits, per chunk, {load w, load b,
+// s_waitcnt vmcnt(0), compute, store}: four serialised L2 round trips per row behind the reductions (round 4: 14.3 -> 12.x us for the
+// 11008 x 1024 rows of a backbone LayerNorm).  Same expressions in the same order as the general kernel: bit-identical results.
+template <int NV, int T, int RPW>
+__global__ __launch_bounds__(256) void layernorm_fast_kernel(const WmLnArgs p) {
+  // RPW rows per wave (A/B: 2 makes the 11 K-row launches of an 8-view forward one round of wave slots instead of 1.34 — measured equal),
+  // all of their loads in flight before the first reduction
+  const int lane = threadIdx.x & 63;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  const long long nrows = (long long)p.groups * p.rows_per_group;
+  if (row0 >= nrows) return;
+  float4 v[RPW][NV], w[NV], b[NV];
+  const float* x[RPW];
+  size_t orow[RPW];
+  bool ok[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    ok[r] = row0 + r < nrows;                              // wave-uniform
+    const long long row = ok[r] ? row0 + r : row0;
+    const int g = (int)(row / p.rows_per_group), q = (int)(row - (long long)g * p.rows_per_group);
+    x[r] = p.x + ((size_t)g * p.in_group + p.in_off + q) * p.ld_in;
+    orow[r] = (size_t)g * p.out_group + p.out_off + q;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[r][i] = *(const float4*)(x[r] + (i * 64 + lane) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    w[i] = *(const float4*)(p.w + (i * 64 + lane) * 4);
+    b[i] = *(const float4*)(p.b + (i * 64 + lane) * 4);
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[r][i].x + v[r][i].y + v[r][i].z + v[r][i].w;
+    const float mean = wave_sum(s) / p.D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float a = v[r][i].x - mean, bb = v[r][i].y - mean, cc = v[r][i].z - mean, d = v[r][i].w - mean;
+      ss += a * a + bb * bb + cc * cc + d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / p.D + p.eps);
+    if (!ok[r]) continue;
+    u16* y = (u16*)p.y + orow[r] * p.ld_out;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float y0 = (v[r][i].x - mean) * rstd * w[i].x + b[i].x, y1 = (v[r][i].y - mean) * rstd * w[i].y + b[i].y;
+      const float y2 = (v[r][i].z - mean) * rstd * w[i].z + b[i].z, y3 = (v[r][i].w - mean) * rstd * w[i].w + b[i].w;
+      uint2 u;
+      u.x = (uint32_t)f2t<T>(y0) | ((uint32_t)f2t<T>(y1) << 16);
+      u.y = (uint32_t)f2t<T>(y2) | ((uint32_t)f2t<T>(y3) << 16);
+      *(uint2*)(y + (i * 64 + lane) * 4) = u;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ QKV post
 // One wave = one token x 4 heads; 16 lanes per head vector (4 elements per lane).
 // attention.py:50-56: split heads, q/k LayerNorm(64, eps 1e-5, affine), 2-D RoPE (rope.py:148-181).
@@ -512,6 +570,23 @@ hipError_t wm_launch_layernorm(const WmLnArgs& a, hipStream_t s) {
   if (a.D % 4 || a.D > 2048 || a.ld_in % 4 || a.ld_out % 4) return hipErrorInvalidValue;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   const int nv = (a.D + 255) / 256;
+  if (a.D == nv * 256 && (nv == 4 || nv == 8) && a.w && a.b && !a.out_f32) {   // the backbone's LayerNorms (D = 1024) and the DPT heads' (D = 2048)
+    // rows per wave: 1; 2 (tuning ln_rpw, D = 1024 only: one round of wave slots instead of 1.34 at 8 views) measured the same 12.5 us
+    // (tools/bench_ln.py) and stays an A/B variant
+    const int rpw = nv == 4 && wm_tuning[WM_TUNE_LN_RPW] == 2 ? 2 : 1;
+    const dim3 g2((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+    if (nv == 4 && rpw == 2) {
+      if (a.dtype == WM_T_BF16) hipLaunchKernelGGL((layernorm_fast_kernel<4, WM_T_BF16, 2>), g2, block, 0, s, a);
+      else hipLaunchKernelGGL((layernorm_fast_kernel<4, WM_T_F16, 2>), g2, block, 0, s, a);
+    } else if (nv == 4) {
+      if (a.dtype == WM_T_BF16) hipLaunchKernelGGL((layernorm_fast_kernel<4, WM_T_BF16, 1>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((layernorm_fast_kernel<4, WM_T_F16, 1>), grid, block, 0, s, a);
+    } else {
+      if (a.dtype == WM_T_BF16) hipLaunchKernelGGL((layernorm_fast_kernel<8, WM_T_BF16, 1>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((layernorm_fast_kernel<8, WM_T_F16, 1>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+  }
   if (nv <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, a);
   else if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, a);
   else if (nv <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, a);
