@@ -146,6 +146,8 @@ def two_pass_overlap(set_overlap, forward, timed, allreduce_max, profile_once=No
         out = forward()
         res[ov] = {"ms": ms, "out": {k: out[k].float().clone() for k in keys if k in out},
                    "profile": profile_once() if profile_once else None}
+        # on record (stderr) before the next mode is attempted: the overlapped form has never run on real links
+        log(f"two-pass gather decision: comm_overlap {ov}: {ms:.3f} ms/step (max over ranks)")
     err, finite = 0.0, True
     for k, a in res[0]["out"].items():
         b = res[1]["out"][k]

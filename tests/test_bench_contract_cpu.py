@@ -42,3 +42,38 @@ def test_timing_kinds_match_the_header():
     documented = {int(x) for x in re.findall(r"(\d+)(?: / (\d+))? =", doc) for x in x if x}
     assert set(b.KINDS) | {4} <= documented, (sorted(b.KINDS), sorted(documented))
     assert b.PEAK_TFLOPS == 2500.0
+
+
+def test_two_pass_gather_decision_logic():
+    """bench.two_pass_overlap (N > 1): both modes are timed, one forward of each is compared, and the overlapped mode is headlined only
+    when it is faster AND agrees with the serial one within the bound; a disagreement or a non-finite output falls back to the serial
+    gather whatever the timing says.  Pure host logic: fake forwards on the CPU."""
+    import torch
+    b = _bench()
+
+    def run(ms0, ms1, delta, nan=False):
+        state = {"mode": None, "set": []}
+        base = {"pts3d": torch.arange(12.0).reshape(1, 1, 2, 2, 3) + 1, "depth": torch.ones(1, 1, 2, 2, 1), "camera_params": torch.ones(1, 1, 9)}
+
+        def set_overlap(v):
+            state["mode"] = v
+            state["set"].append(v)
+
+        def fwd():
+            o = {k: v.clone() for k, v in base.items()}
+            if state["mode"] == 1:
+                o["pts3d"] = o["pts3d"] * (1.0 + delta)
+                if nan:
+                    o["depth"][0, 0, 0, 0, 0] = float("nan")
+            return o
+        pick, ms, info = b.two_pass_overlap(set_overlap, fwd, lambda: (ms0 if state["mode"] == 0 else ms1), lambda x: x)
+        assert state["set"][:2] == [0, 1] and state["set"][-1] == pick      # serial first; the tuning is left at the choice
+        assert ms == (ms0, ms1)[pick] and info["chosen_comm_overlap"] == pick
+        return pick, info
+
+    assert run(10.0, 9.0, 1e-4)[0] == 1                 # faster and within the bound
+    assert run(10.0, 11.0, 1e-4)[0] == 0                # slower
+    pick, info = run(10.0, 5.0, 1e-2)                   # faster but disagrees: not headlined
+    assert pick == 0 and not info["comparison_passed"]
+    pick, info = run(10.0, 5.0, 0.0, nan=True)          # non-finite output
+    assert pick == 0 and not info["comparison_passed"]
