@@ -49,7 +49,7 @@ EXPORTS = [
     "wm_create", "wm_destroy", "wm_last_error", "wm_set_weight", "wm_finalize_weights", "wm_host_resample_pos",
     "wm_workspace_bytes", "wm_reserve", "wm_set_workspace", "wm_missing_name", "wm_share_weights", "wm_forward", "wm_forward_sharded", "wm_rccl_unique_id", "wm_comm_init_rccl",
     "wm_local_group_create", "wm_local_group_destroy", "wm_comm_init_local", "wm_allgather", "wm_profile_enable", "wm_profile_read",
-    "wm_op_gemm", "wm_op_gemm_qkv", "wm_op_attention", "wm_op_layernorm", "wm_op_qkv_post", "wm_op_conv", "wm_op_bilinear",
+    "wm_op_gemm", "wm_op_gemm_resid_ln", "wm_op_gemm_qkv", "wm_op_attention", "wm_op_layernorm", "wm_op_qkv_post", "wm_op_conv", "wm_op_bilinear",
     "wm_op_linear_f32", "wm_host_to_16", "wm_set_tuning", "wm_op_attention_split", "wm_op_attention_ex", "wm_op_attention_flag_count", "wm_op_gs_splat", "wm_op_conv3x3_up", "wm_depth_to_world", "wm_confidence_mask", "wm_confidence_mask_workspace_bytes", "wm_preprocess_image", "wm_preprocess_image_size",
     "wm_preprocess_image_workspace_bytes", "wm_rasterize_splats", "wm_rasterize_workspace_bytes", "wm_prune_gs", "wm_prune_gs_workspace_bytes", "wm_op_up_conv_n32",
 ]
@@ -97,6 +97,7 @@ def lib() -> C.CDLL:
     L.wm_profile_enable.argtypes = [vp, i32]
     L.wm_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.wm_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.wm_op_gemm_resid_ln.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, C.POINTER(i32), vp]
     L.wm_op_gemm_qkv.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     L.wm_op_attention.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.wm_op_attention_split.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]

@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -783,6 +783,220 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const WmGemmArgs p) {
   epilogue16<T, EPI, SM, SN>(p, acc, m0 + wr * WROWS, n0 + wc * 64, lane, p.M);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// WM_EPI_RESID + the following LayerNorm (see WmGemmArgs::ln_out).  Numerics: the row statistics are combined from partials
+// (64 columns per wave -> 256 per tile -> 1024 per row) with the equal-count form of Chan's update, mean = avg(mean_k),
+// M2 = sum(M2_k) + n_k sum((mean_k - mean)^2): as accurate as the two-pass form of layernorm_kernel, not bit-identical to it.
+// ln_norm() is the one expression both this epilogue and the fallback kernel apply, with explicit roundings and one fma.
+typedef __attribute__((address_space(1))) unsigned long long wm_gu64;
+typedef __attribute__((address_space(1))) int wm_gi32;
+#define WM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ float ln_norm(float v, float mean, float rstd, float w, float b) {
+  return __builtin_fmaf(__fmul_rn(__fsub_rn(v, mean), rstd), w, b);
+}
+// (mean, M2) of four equal-count partials; cnt = elements per partial
+__device__ __forceinline__ void ln_combine4(const float (&m)[4], const float (&q)[4], float cnt, float& mean, float& M2) {
+  mean = __fmul_rn(__fadd_rn(__fadd_rn(m[0], m[1]), __fadd_rn(m[2], m[3])), 0.25f);
+  const float d0 = __fsub_rn(m[0], mean), d1 = __fsub_rn(m[1], mean), d2 = __fsub_rn(m[2], mean), d3 = __fsub_rn(m[3], mean);
+  const float dd = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fadd_rn(__fmul_rn(d2, d2), __fmul_rn(d3, d3)));
+  M2 = __fadd_rn(__fadd_rn(__fadd_rn(q[0], q[1]), __fadd_rn(q[2], q[3])), __fmul_rn(cnt, dd));
+}
+constexpr int WM_LN_SPIN_LIMIT = 4000;   // polls of ~64 cycles each: ~120 us, far beyond a band's skew when its four blocks are resident
+
+// acc holds this wave's (SM x 16 rows) x 64 columns of acc; on return X (and the tap half) are updated and, unless the rendezvous
+// timed out, ln_out holds the normalised rows of this block's 256 columns.
+template <int T, int SM>
+__device__ __forceinline__ void epilogue_resid_ln(const WmGemmArgs& p, f32x4 (&acc)[SM][4], char* smem, int tid, int lane, int wr, int wc,
+                                                  int band, int nt, int rowb, int colb, int rl0, int mlim) {
+  const int l15 = lane & 15, lq = lane >> 4;
+  float4 bs4[4], gm4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = colb + j * 16 + 4 * lq;
+    bs4[j] = p.bias ? *(const float4*)(p.bias + col) : make_float4(0, 0, 0, 0);
+    gm4[j] = *(const float4*)(p.gamma + col);
+  }
+  // ---- A: new values gamma (acc + bias) + X into acc.  The X stores are NOT issued yet: the block's signal has to wait for every store
+  // in front of it, so the 8-byte statistics go out first and the bulk stores (phase X below) run while the band's other blocks arrive
+  float4 old[2][4];
+  auto load_old = [&](int i, float4 (&o)[4]) {
+    const int row = rowb + i * 16 + l15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = row < mlim ? *(const float4*)((const float*)p.C + (size_t)row * p.ldc + colb + j * 16 + 4 * lq) : make_float4(0, 0, 0, 0);
+  };
+  load_old(0, old[0]);
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    if (rowb + i * 16 >= mlim) break;
+    if (i + 1 < SM) load_old(i + 1, old[(i + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 o = old[i & 1][j], gm = gm4[j], bs = bs4[j];
+      acc[i][j] = f32x4{o.x + gm.x * (acc[i][j][0] + bs.x), o.y + gm.y * (acc[i][j][1] + bs.y), o.z + gm.z * (acc[i][j][2] + bs.z), o.w + gm.w * (acc[i][j][3] + bs.w)};
+    }
+  }
+  // ---- B: per row (mean, M2) over this wave's 64 columns -> LDS [tile row][wc]
+  float2* lst = (float2*)smem;     // [256][4] (mean, M2): the K-tile ring is dead
+  int* lflag = (int*)(smem + 256 * 4 * 8);
+  __syncthreads();                 // every wave is out of the K loop: the ring may be overwritten
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    if (rowb + i * 16 >= mlim) break;   // wave-uniform
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s1 += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+    s1 += __shfl_xor(s1, 16);
+    const float mw = __fmul_rn(xhalf_sum(s1), 1.0f / 64.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = acc[i][j][e] - mw; s2 = __builtin_fmaf(d, d, s2); }
+    s2 += __shfl_xor(s2, 16);
+    s2 = xhalf_sum(s2);
+    if (lq == 0) lst[(rl0 + i * 16 + l15) * 4 + wc] = make_float2(mw, s2);
+  }
+  __syncthreads();
+  // ---- C: the tile's (mean, M2) per row; the wc == 0 waves publish them (8-byte sc1 stores), then one arrival per block
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    if (rowb + i * 16 >= mlim) break;
+    const float4 a0 = *(const float4*)(lst + (rl0 + i * 16 + l15) * 4), a1 = *(const float4*)(lst + (rl0 + i * 16 + l15) * 4 + 2);
+    const float m[4] = {a0.x, a0.z, a1.x, a1.z}, q[4] = {a0.y, a0.w, a1.y, a1.w};
+    float tmean, tm2;
+    ln_combine4(m, q, 64.0f, tmean, tm2);
+    const int row = rowb + i * 16 + l15;
+    if (wc == 0 && lq == 0 && row < mlim) {
+      const unsigned long long bits = ((unsigned long long)__builtin_bit_cast(unsigned, tm2) << 32) | __builtin_bit_cast(unsigned, tmean);
+      __hip_atomic_store((wm_gu64*)(p.ln_stats + ((size_t)row * 4 + nt) * 2), bits, WM_RLX_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the block signals
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add((wm_gi32*)(p.ln_sync + band * 2), 1, WM_RLX_AGENT);
+  // ---- X: the residual stream (and the tap half), while the other three blocks of the band arrive
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    if (rowb + i * 16 >= mlim) break;
+    const int row = rowb + i * 16 + l15;
+    if (row < mlim) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 nv = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        *(float4*)((float*)p.C + (size_t)row * p.ldc + colb + j * 16 + 4 * lq) = nv;
+        if (p.C2) *(float4*)(p.C2 + (size_t)row * p.ldc2 + colb + j * 16 + 4 * lq) = nv;
+      }
+    }
+  }
+  int ok = 0;
+  if (tid == 0) {
+    int spins = 0;
+    while (true) {
+      if (__hip_atomic_load((wm_gi32*)(p.ln_sync + band * 2), WM_RLX_AGENT) >= 4) { ok = 1; break; }
+      if (++spins > WM_LN_SPIN_LIMIT) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store((wm_gi32*)(p.ln_fallback + band), 1, WM_RLX_AGENT);
+    *lflag = ok;
+  }
+  __syncthreads();
+  ok = *lflag;
+  // ---- D: the row's statistics from the four tiles' partials (sc1 loads of sc1-stored, drained bytes), normalise, 16-bit stores
+  if (ok) {
+    float4 w4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w4[j] = *(const float4*)(p.ln_w + colb + j * 16 + 4 * lq);
+      b4[j] = *(const float4*)(p.ln_b + colb + j * 16 + 4 * lq);
+    }
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+      if (rowb + i * 16 >= mlim) break;
+      const int row = rowb + i * 16 + l15;
+      const int rr = row < mlim ? row : mlim - 1;
+      float m[4], q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long bits = __hip_atomic_load((wm_gu64*)(p.ln_stats + ((size_t)rr * 4 + k) * 2), WM_RLX_AGENT);
+        m[k] = __builtin_bit_cast(float, (unsigned)bits); q[k] = __builtin_bit_cast(float, (unsigned)(bits >> 32));
+      }
+      float mean, M2;
+      ln_combine4(m, q, 256.0f, mean, M2);
+      const float rstd = 1.0f / sqrtf(__fadd_rn(__fmul_rn(M2, 1.0f / 1024.0f), p.ln_eps));
+      uint2 u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y0 = ln_norm(acc[i][j][0], mean, rstd, w4[j].x, b4[j].x), y1 = ln_norm(acc[i][j][1], mean, rstd, w4[j].y, b4[j].y);
+        const float y2 = ln_norm(acc[i][j][2], mean, rstd, w4[j].z, b4[j].z), y3 = ln_norm(acc[i][j][3], mean, rstd, w4[j].w, b4[j].w);
+        u[j].x = (uint32_t)f2t<T>(y0) | ((uint32_t)f2t<T>(y1) << 16);
+        u[j].y = (uint32_t)f2t<T>(y2) | ((uint32_t)f2t<T>(y3) << 16);
+      }
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {   // 16-B stores of 64-B row segments (see the T16 epilogue)
+        swap16(u[2 * jp].x, u[2 * jp + 1].x);
+        swap16(u[2 * jp].y, u[2 * jp + 1].y);
+        const int col = colb + (2 * jp + (lq & 1)) * 16 + 4 * (lq & 2);
+        if (row < mlim) *(uint4*)((u16*)p.ln_out + (size_t)row * p.ln_ld + col) = make_uint4(u[2 * jp].x, u[2 * jp].y, u[2 * jp + 1].x, u[2 * jp + 1].y);
+      }
+    }
+  }
+  // ---- E: departure; the band's last block to leave re-arms the counters for the next launch
+  __syncthreads();
+  if (tid == 0) {
+    const int d = __hip_atomic_fetch_add((wm_gi32*)(p.ln_sync + band * 2 + 1), 1, WM_RLX_AGENT);
+    if (d == 3) {
+      __hip_atomic_store((wm_gi32*)(p.ln_sync + band * 2), 0, WM_RLX_AGENT);
+      __hip_atomic_store((wm_gi32*)(p.ln_sync + band * 2 + 1), 0, WM_RLX_AGENT);
+    }
+  }
+}
+
+#ifdef WM_GEMM_STAMPS
+__device__ int wm_ln_fallback_count;
+#endif
+// Bands whose rendezvous timed out (ln_fallback set): LayerNorm of their rows from X and the published partials, the epilogue's arithmetic.
+template <int T>
+__global__ __launch_bounds__(256) void gemm_ln_fallback_kernel(const WmGemmArgs p, int bands, int full_units) {
+  const int band = blockIdx.x;
+  if (__hip_atomic_load((wm_gi32*)(p.ln_fallback + band), WM_RLX_AGENT) == 0) return;   // block-uniform
+  int u0, S;
+  if (p.sched_bands > 0) {
+    u0 = (int)((long long)band * p.sched_units / bands);
+    S = (int)((long long)(band + 1) * p.sched_units / bands) - u0;
+  } else {
+    u0 = band * full_units; S = full_units;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef WM_GEMM_STAMPS
+  if (threadIdx.x == 0) atomicAdd(&wm_ln_fallback_count, 1);   // diagnostic build: bands recomputed since the last read
+#endif
+  const int r1 = (u0 + S) * 16 < p.M ? (u0 + S) * 16 : p.M;
+  for (int row = u0 * 16 + wave; row < r1; row += 4) {
+    float m[4], q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long bits = __hip_atomic_load((wm_gu64*)(p.ln_stats + ((size_t)row * 4 + k) * 2), WM_RLX_AGENT);
+      m[k] = __builtin_bit_cast(float, (unsigned)bits); q[k] = __builtin_bit_cast(float, (unsigned)(bits >> 32));
+    }
+    float mean, M2;
+    ln_combine4(m, q, 256.0f, mean, M2);
+    const float rstd = 1.0f / sqrtf(__fadd_rn(__fmul_rn(M2, 1.0f / 1024.0f), p.ln_eps));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const float4 v = *(const float4*)((const float*)p.C + (size_t)row * p.ldc + c);
+      const float4 w = *(const float4*)(p.ln_w + c), b = *(const float4*)(p.ln_b + c);
+      uint2 u;
+      u.x = (uint32_t)f2t<T>(ln_norm(v.x, mean, rstd, w.x, b.x)) | ((uint32_t)f2t<T>(ln_norm(v.y, mean, rstd, w.y, b.y)) << 16);
+      u.y = (uint32_t)f2t<T>(ln_norm(v.z, mean, rstd, w.z, b.z)) | ((uint32_t)f2t<T>(ln_norm(v.w, mean, rstd, w.w, b.w)) << 16);
+      *(uint2*)((u16*)p.ln_out + (size_t)row * p.ln_ld + c) = u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store((wm_gi32*)(p.ln_fallback + band), 0, WM_RLX_AGENT);
+}
+
 #ifdef WM_GEMM_STAMPS
 // diagnostic build only (make stamps): wave 0 of every block records, on the 100 MHz s_memrealtime counter, its entry, the start and
 // the end of its K loop and its exit (after its own stores have drained), the shader clock count of the loop and the CU it ran on;
@@ -1115,6 +1329,12 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   if (DBG == 5 && acc[0][0][0] != 1.2345e-30f) return;  // timing experiment: no epilogue
   {
     const int rowb = m0 + (wr ? 16 * S0 : 0), rend = rowb + 16 * Sw;
+    if constexpr (EPI == WM_EPI_RESID && DBG == 0 && QI == 3) {   // (192-row tile only: on the 256-row tile the fused epilogue does not fit 256 registers)
+      if (p.ln_out) {   // block-uniform: the following LayerNorm rides in this epilogue
+        epilogue_resid_ln<T, SM>(p, acc, smem, tid, lane, wr, wc, band, nt, rowb, n0 + wc * 64, wr ? 16 * S0 : 0, rend < p.M ? rend : p.M);
+        return;
+      }
+    }
     epilogue16<T, EPI, SM, SN>(p, acc, rowb, n0 + wc * 64, lane, rend < p.M ? rend : p.M);
   }
 #ifdef WM_GEMM_STAMPS
@@ -1306,18 +1526,48 @@ void pick_sched(const WmGemmArgs& a, int ncu, int forced_cfg, int& cfg, int& ban
 
 }  // namespace
 
-hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
-  if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (a.K <= 0 || a.K % 64 != 0 || a.N % 4 != 0) return hipErrorInvalidValue;
-  if ((a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;  // 16-B aligned rows
-  if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
-  if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
-  if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
-  int cfg = pick_cfg(a);
-  int sched_b = 0;
+static int wm_ncu() {
+  static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+  return ncu;
+}
+// tile configuration, row-band schedule (0 = full-height grid) and whether the launch is a ping-pong v2 / v3 one
+static void plan_gemm(const WmGemmArgs& a, int& cfg, int& sched_b, bool& pp2_out);
+
+bool wm_gemm_fuses_ln(const WmGemmArgs& a) {
+  if (!a.ln_out || a.epi != WM_EPI_RESID || a.N != 1024 || !a.ln_w || !a.ln_b || !a.ln_stats || !a.ln_sync || !a.ln_fallback || !a.gamma) return false;
+  // OPT-IN (tuning ln_fuse = 1).  Built and proven in round 4 (tests/test_gpu_ops.py::test_gemm_residual_with_fused_layernorm, zero fallbacks in
+  // the forward: tools/ln_fallback_count.py) and measured: per launch -2.5 us (proj) / -0.8 us (fc2) against GEMM + LayerNorm kernel in isolation,
+  // and between -0.15 and +0.87 ms on the 8-view forward by box (interleaved: 52.38 / 52.50 fused vs 52.39 / 52.74 on one box, 53.49 vs 52.62 on
+  // another): the rendezvous' signal -> poll -> partial loads chain costs what the LayerNorm kernel's second read of a stream that the residual
+  // epilogue has just left in the memory-side cache costs.  No gain to ship a second synchronisation structure for: off by default.
+  if (wm_tuning[WM_TUNE_LN_FUSE] != 1 || (a.ln_ld & 7) || (a.ldc & 3)) return false;
+  int cfg, sched_b; bool pp2;
+  plan_gemm(a, cfg, sched_b, pp2);
+  if (!pp2 || cfg != 5) return false;   // the 192-row tile's kernel carries the fused epilogue
+  const int bm = cfg == 4 ? 256 : 192;
+  const long bands = sched_b > 0 ? sched_b : (a.M + bm - 1) / bm;
+  return bands * 4 <= wm_ncu();   // every block of the launch resident at once (one per CU): the rendezvous of a band's four blocks cannot wait on an undispatched one
+}
+
+hipError_t wm_launch_gemm_ln_fallback(const WmGemmArgs& a, hipStream_t s) {
+  if (!wm_gemm_fuses_ln(a)) return hipSuccess;
+  int cfg, sched_b; bool pp2;
+  plan_gemm(a, cfg, sched_b, pp2);
+  const int bm = cfg == 4 ? 256 : 192;
+  const int bands = sched_b > 0 ? sched_b : (a.M + bm - 1) / bm;
+  WmGemmArgs b = a;
+  b.sched_bands = sched_b; b.sched_units = (a.M + 15) / 16;
+  if (a.dtype == WM_T_BF16) hipLaunchKernelGGL((gemm_ln_fallback_kernel<WM_T_BF16>), dim3(bands), dim3(256), 0, s, b, bands, bm / 16);
+  else hipLaunchKernelGGL((gemm_ln_fallback_kernel<WM_T_F16>), dim3(bands), dim3(256), 0, s, b, bands, bm / 16);
+  return hipGetLastError();
+}
+
+static void plan_gemm(const WmGemmArgs& a, int& cfg, int& sched_b, bool& pp2_out) {
+  cfg = pick_cfg(a);
+  sched_b = 0;
   {
     // ping-pong v2 launches only (launch_T): backbone epilogues on the 256- / 192-row tiles
-    static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    const int ncu = wm_ncu();
     const int pp = wm_tuning[WM_TUNE_GEMM_PP];
     const bool pp2 = (cfg == 4 || cfg == 5) && (pp < 0 || pp == 1 || pp == 2 || pp == 4) && (a.epi == WM_EPI_F32 || a.epi == WM_EPI_T16 || a.epi == WM_EPI_GELU_T16 || a.epi == WM_EPI_RESID || a.epi == WM_EPI_QKV);
     const int ts = wm_tuning[WM_TUNE_GEMM_SCHED];   // -1 choose, 0 off (full-height tiles), > 0 that many bands
@@ -1333,7 +1583,23 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
       // bands taller than the tile, or shorter than the kernel's instantiations go (a wave group drops at most 2 units): full-height grid
       if (sched_b <= 0 || (U + sched_b - 1) / sched_b > full || U / sched_b < full - 4) sched_b = 0;
     }
+    pp2_out = pp2 && wm_tuning[WM_TUNE_GEMM_PP] != 0;
+    static const int pp_env = [] { const char* e = wm_env("WM_GEMM_PP"); return e ? atoi(e) : 1; }();
+    if (wm_tuning[WM_TUNE_GEMM_PP] < 0 && !pp_env) pp2_out = false;
   }
+}
+
+hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (a.K <= 0 || a.K % 64 != 0 || a.N % 4 != 0) return hipErrorInvalidValue;
+  if ((a.lda & 7) || (a.ldw & 7)) return hipErrorInvalidValue;  // 16-B aligned rows
+  if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
+  if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
+  if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
+  int cfg, sched_b;
+  bool is_pp2;
+  plan_gemm(a, cfg, sched_b, is_pp2);
+  const bool fuse_ln = wm_gemm_fuses_ln(a);
   const int gb = wm_tuning[WM_TUNE_GEMM_GROUP] >= 0 ? wm_tuning[WM_TUNE_GEMM_GROUP] : 6;  // row bands per supertile: 6 measured 2-3 % ahead of 4 / 8 at 32 views, equal at 8 (tools/bench_gemm_group.py)
   if (a.epi == WM_EPI_QKV) {
     if (a.qkv.tokens_per_view <= 0 || a.qkv.grid_w <= 0 || a.M >= (1 << 20) || a.qkv.tokens_per_view >= (1 << 16)) return hipErrorInvalidValue;
@@ -1347,6 +1613,7 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   WmGemmArgs c = a;
   c.group_bands = gb;
   c.sched_bands = sched_b; c.sched_units = (a.M + 15) / 16;
+  if (!fuse_ln) c.ln_out = nullptr;   // the kernel takes the fused epilogue iff ln_out is set
   return c.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(c, cfg, s) : launch_T<WM_T_F16>(c, cfg, s);
 }
 
@@ -1354,6 +1621,12 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
 extern "C" int wm_debug_gemm_stamps(unsigned long long* host_out, int nblocks) {
   if (nblocks > 8192) nblocks = 8192;
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wm_gemm_stamp_buf), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int wm_debug_ln_fallback_count() {   // bands the fused-LayerNorm fallback kernel recomputed since the last call (then reset)
+  int v = -1, z = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(wm_ln_fallback_count), 4) != hipSuccess) return -1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(wm_ln_fallback_count), &z, 4);
+  return v;
 }
 extern "C" int wm_debug_gemm_stamps_clear() {
   void* d = nullptr;

@@ -52,8 +52,23 @@ struct WmGemmArgs {
   int rows_per_group, out_group, out_off, accumulate, out16, relu;  // WM_EPI_ROWMAP_ADD (out16: C is 16-bit, no accumulate; relu before add)
   int ct_k, ct_cout, ct_gh, ct_gw;                     // WM_EPI_CONVT
   WmQkvArgs qkv;                                       // WM_EPI_QKV (qkv.qkv unused; qkv.H*64 = D)
+  // WM_EPI_RESID with the FOLLOWING LayerNorm fused into the epilogue (round 4; block.py:44,61 behind :90-92): when ln_out is set and
+  // wm_gemm_fuses_ln(args) holds (N = 1024 = four column tiles, every block of the launch resident at once), the epilogue keeps the new
+  // residual values in registers, the four column tiles of a row band exchange per-row (mean, M2) partials through ln_stats, and every
+  // block writes LayerNorm(x) * ln_w + ln_b for its own 256 columns as a 16-bit tensor — the LayerNorm kernel's second read of the
+  // stream is gone.  The rendezvous is a bounded spin; a block that gives up sets ln_fallback[band] and wm_launch_gemm_ln_fallback (always
+  // launched behind, normally a no-op) redoes such bands from X and the partials with the same arithmetic.
+  void* ln_out; int ln_ld;                             // 16-bit [M][ln_ld] (the GEMM's operand type)
+  const float* ln_w; const float* ln_b; float ln_eps;
+  float* ln_stats;                                     // [M][4][2] fp32 (mean, M2) of the row over each column tile
+  int* ln_sync;                                        // [bands][2] arrivals / departures of a band's blocks, zero between launches
+  int* ln_fallback;                                    // [bands]
 };
 hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s);
+// whether wm_launch_gemm(a) would take the fused-LayerNorm epilogue (a.ln_out set, shape / residency conditions): the caller skips its LayerNorm launch
+bool wm_gemm_fuses_ln(const WmGemmArgs& a);
+// behind a fused launch, on the same stream: recomputes the bands whose rendezvous timed out (grid = the launch's row bands)
+hipError_t wm_launch_gemm_ln_fallback(const WmGemmArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ attention (attention.hip)
 #define WM_ATTN_MAX_SPLITS_C 8
@@ -234,6 +249,6 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
                               const float* weights, int N, float voxel, float* o_means, float* o_quats, float* o_scales, float* o_opac,
                               float* o_sh, int* K_out, void* workspace, size_t ws_bytes, hipStream_t s);
 
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

@@ -290,6 +290,10 @@ std::vector<std::pair<std::string, size_t>> arena_layout(const wm_handle* h, con
   // sticky fallback hints of the fast attention kernels (WmAttnArgs::unit_hint): one int per launch block, per attention call site
   // (DINO + frame + global blocks) x up to 3 launches (the piecewise form under the overlapped gather); zeroed by wm_reserve
   add("ATT_HINT", (size_t)(c.dino_depth + 2 * c.depth) * 3 * wm_attention_max_blocks((int)Mx, d.P < d.Td ? d.P : d.Td, d.heads) * 4);
+  // fused LayerNorm of the residual GEMMs (WmGemmArgs::ln_out): per-row partials of the four column tiles, per-band arrival / departure
+  // counters and fallback flags (zeroed by wm_reserve; the kernels leave the counters and flags at zero)
+  add("LN_STATS", Mx * 4 * 2 * 4);
+  add("LN_SYNC", (Mx / 16 + 2) * 3 * 4);
   add("ATT_STAT", (size_t)(c.dino_depth + 2 * c.depth) * 3 * 4);   // WmAttnArgs::unit_stat, one counter per (call site, launch)
   add("ZERO256", 256);  // zero page for the out-of-image halo pieces of the DMA-fed conv (conv_n32.hip); cleared at the start of every forward
   add("rope_cos", (size_t)(std::max(d.gh, d.gw) + 1) * 16 * 4);
@@ -440,7 +444,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -675,6 +679,7 @@ wm_status plan(wm_handle* h, const Dims& d) {
     h->att_general_ttl.assign(n, 0);
     HIPCHK(h, hipMemset(h->buf["ATT_STAT"], 0, (size_t)n * 4));
   }
+  HIPCHK(h, hipMemset(h->buf["LN_SYNC"], 0, ((size_t)d.Mx / 16 + 2) * 3 * 4));
   // the fast attention kernels' sticky fallback hints start empty for a new shape (they index launch blocks)
   HIPCHK(h, hipMemset(h->buf["ATT_HINT"], 0, (size_t)(c.dino_depth + 2 * c.depth) * 3 * wm_attention_max_blocks((int)d.Mx, d.P < d.Td ? d.P : d.Td, d.heads) * 4));
   // DINO pos-embed for this grid (vision_transformer.py:175-207)
@@ -796,14 +801,18 @@ struct Ctx {
   } while (0)
 
 wm_status gemm(Ctx& c, int dt, int epi, const void* A, int lda, const void* Wp, int ldw, void* C, int ldc, const float* bias,
-               const float* gamma, int M, int N, int K, WmGemmArgs* extra = nullptr, int prof_kind = -1) {
+               const float* gamma, int M, int N, int K, WmGemmArgs* extra = nullptr, int prof_kind = -1, bool* ln_fused = nullptr) {
   WmGemmArgs a;
   if (extra) a = *extra; else memset(&a, 0, sizeof(a));
   a.A = A; a.W = Wp; a.C = C; a.bias = bias; a.gamma = gamma;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.dtype = dt; a.epi = epi;
   // timing kinds by kernel instantiation: the three epilogues that carry the transformer blocks, the rest under 2
   ProfScope ps(c.h, prof_kind >= 0 ? prof_kind : epi == WM_EPI_QKV ? 5 : epi == WM_EPI_RESID ? 6 : epi == WM_EPI_GELU_T16 ? 7 : 2, c.s);
+  const bool fuse = a.ln_out != nullptr && wm_gemm_fuses_ln(a);
+  if (!fuse) a.ln_out = nullptr;
+  if (ln_fused) *ln_fused = fuse;
   LCHK(c, wm_launch_gemm(a, c.s));
+  if (fuse) LCHK(c, wm_launch_gemm_ln_fallback(a, c.s));   // bands whose rendezvous timed out (normally none: every block exits at entry)
   return WM_OK;
 }
 
@@ -820,8 +829,11 @@ wm_status layernorm(Ctx& c, const float* x, int ld_in, void* y, int ld_out, cons
 // Block.forward (block.py:72-93) on the fp32 residual stream X [M][D]; seq_len = attention span.
 // tap_half: when non-null, the block's output (the value its last GEMM stores to X) is also written to tap_half[row * 2D + col]
 // by that GEMM's epilogue — the cat([frame_out, global_out], -1) of visual_transformer.py:337-339 without a copy pass.
+// next_norm1: name prefix of the block that follows on the same stream X ("" = none): its norm1 is then computed by this block's fc2
+// epilogue when the shape allows (wm_gemm_fuses_ln) and *ln1_ready tells the caller to pass ln1_done to that block.
 wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_len, int heads, float eps, bool qk_norm,
-                         bool rope, int tokens_per_view, int patch_start, bool is_global, float* tap_half = nullptr) {
+                         bool rope, int tokens_per_view, int patch_start, bool is_global, float* tap_half = nullptr,
+                         bool ln1_done = false, const std::string& next_norm1 = std::string(), bool* ln1_ready = nullptr) {
   wm_handle* h = c.h;
   const Dims& d = c.d;
   const int D = d.D, dt = c.bdt;
@@ -832,8 +844,18 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
   void* O16 = B<void>(h, "O16");
   void* H16 = B<void>(h, "H16");
   wm_status st;
-  st = layernorm(c, X, D, A16, D, F(h, p + "norm1.weight"), F(h, p + "norm1.bias"), D, eps, 1, M, 0, 0, 0, 0, 0, dt);
-  if (st) return st;
+  if (ln1_ready) *ln1_ready = false;
+  if (!ln1_done) {
+    st = layernorm(c, X, D, A16, D, F(h, p + "norm1.weight"), F(h, p + "norm1.bias"), D, eps, 1, M, 0, 0, 0, 0, 0, dt);
+    if (st) return st;
+  }
+  // the residual GEMMs carry the LayerNorm that follows them when the launch allows it (gemm.hip epilogue_resid_ln)
+  auto fuse_args = [&](WmGemmArgs& ex, const float* w, const float* b) {
+    ex.ln_out = A16; ex.ln_ld = D; ex.ln_w = w; ex.ln_b = b; ex.ln_eps = eps;
+    ex.ln_stats = B<float>(h, "LN_STATS");
+    int* sync = B<int>(h, "LN_SYNC");
+    ex.ln_sync = sync; ex.ln_fallback = sync + ((size_t)d.Mx / 16 + 2) * 2;
+  };
   {  // QKV projection with q/k-norm + RoPE + head-major relayout fused into the epilogue (attention.py:50-56)
     WmGemmArgs ex;
     memset(&ex, 0, sizeof(ex));
@@ -971,17 +993,28 @@ wm_status backbone_block(Ctx& c, const std::string& p, float* X, int M, int seq_
       LCHK(c, wm_launch_attention(a, c.s));
     }
   }
-  st = gemm(c, dt, WM_EPI_RESID, O16, D, W16(h, p + "attn.proj.weight"), D, X, D, F(h, p + "attn.proj.bias"), F(h, p + "ls1.gamma"), M, D, D);
-  if (st) return st;
-  st = layernorm(c, X, D, A16, D, F(h, p + "norm2.weight"), F(h, p + "norm2.bias"), D, eps, 1, M, 0, 0, 0, 0, 0, dt);
-  if (st) return st;
+  {
+    WmGemmArgs ex;
+    memset(&ex, 0, sizeof(ex));
+    fuse_args(ex, F(h, p + "norm2.weight"), F(h, p + "norm2.bias"));
+    bool fused = false;
+    st = gemm(c, dt, WM_EPI_RESID, O16, D, W16(h, p + "attn.proj.weight"), D, X, D, F(h, p + "attn.proj.bias"), F(h, p + "ls1.gamma"), M, D, D, &ex, -1, &fused);
+    if (st) return st;
+    if (!fused) {
+      st = layernorm(c, X, D, A16, D, F(h, p + "norm2.weight"), F(h, p + "norm2.bias"), D, eps, 1, M, 0, 0, 0, 0, 0, dt);
+      if (st) return st;
+    }
+  }
   const int Hd = c.h->cfg.mlp_ratio * D;
   st = gemm(c, dt, WM_EPI_GELU_T16, A16, D, W16(h, p + "mlp.fc1.weight"), D, H16, Hd, F(h, p + "mlp.fc1.bias"), nullptr, M, Hd, D);
   if (st) return st;
   WmGemmArgs ex;
   memset(&ex, 0, sizeof(ex));
   ex.C2 = tap_half; ex.ldc2 = 2 * D;
-  st = gemm(c, dt, WM_EPI_RESID, H16, Hd, W16(h, p + "mlp.fc2.weight"), Hd, X, D, F(h, p + "mlp.fc2.bias"), F(h, p + "ls2.gamma"), M, D, Hd, &ex);
+  bool fused = false;
+  if (!next_norm1.empty()) fuse_args(ex, F(h, next_norm1 + "norm1.weight"), F(h, next_norm1 + "norm1.bias"));
+  st = gemm(c, dt, WM_EPI_RESID, H16, Hd, W16(h, p + "mlp.fc2.weight"), Hd, X, D, F(h, p + "mlp.fc2.bias"), F(h, p + "ls2.gamma"), M, D, Hd, &ex, -1, &fused);
+  if (ln1_ready) *ln1_ready = fused;
   return st;
 }
 
@@ -1292,9 +1325,13 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
     if (st) return st;
   }
   LCHK(c, wm_launch_dino_tokens(nullptr, F(h, dn + "cls_token"), F(h, dn + "register_tokens"), B<float>(h, "dino_pos"), Xd, n, d.hw, d.R, D, s));
-  for (int i = 0; i < cf.dino_depth; ++i) {
-    st = backbone_block(c, dn + "blocks." + std::to_string(i) + ".", Xd, d.Md, d.Td, cf.dino_heads, 1e-6f, false, false, d.Td, 0, false);
-    if (st) return st;
+  {
+    bool ln1 = false;
+    for (int i = 0; i < cf.dino_depth; ++i) {
+      const std::string nxt = i + 1 < cf.dino_depth ? dn + "blocks." + std::to_string(i + 1) + "." : std::string();
+      st = backbone_block(c, dn + "blocks." + std::to_string(i) + ".", Xd, d.Md, d.Td, cf.dino_heads, 1e-6f, false, false, d.Td, 0, false, nullptr, ln1, nxt, &ln1);
+      if (st) return st;
+    }
   }
   // final LN, patch tokens only, straight into the multi-view token buffer
   st = layernorm(c, Xd, D, Xv, D, F(h, dn + "norm.weight"), F(h, dn + "norm.bias"), D, 1e-6f, n, d.hw, d.Td, 1 + d.R, d.P, d.psi, 1, 0);
@@ -1337,13 +1374,17 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
 
   // ---- a7-a10: 24 x (frame block, global block) + taps (visual_transformer.py:309-339)
   int tap_i = 0;
+  bool vgt_ln1 = false;   // A16 already holds the coming block's norm1(X): the previous block's fc2 epilogue wrote it
   for (int i = 0; i < cf.depth; ++i) {
     const bool is_tap = tap_i < 4 && i == cf.intermediate_idxs[tap_i];
     float* tap = is_tap ? B<float>(h, ("tap" + std::to_string(tap_i)).c_str()) : nullptr;
-    st = backbone_block(c, v + "frame_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.P, cf.num_heads, 1e-5f, true, true, d.P, d.psi, false, tap);
+    // (frame and global blocks alternate on the same token buffer: each block's fc2 epilogue computes the next block's norm1)
+    const std::string gname = v + "global_blocks." + std::to_string(i) + ".";
+    const std::string fnext = i + 1 < cf.depth ? v + "frame_blocks." + std::to_string(i + 1) + "." : std::string();
+    st = backbone_block(c, v + "frame_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.P, cf.num_heads, 1e-5f, true, true, d.P, d.psi, false, tap,
+                        vgt_ln1, gname, &vgt_ln1);
     if (st) return st;
-    st = backbone_block(c, v + "global_blocks." + std::to_string(i) + ".", Xv, d.Mv, d.Mv, cf.num_heads, 1e-5f, true, true, d.P, d.psi, true,
-                        tap ? tap + D : nullptr);
+    st = backbone_block(c, gname, Xv, d.Mv, d.Mv, cf.num_heads, 1e-5f, true, true, d.P, d.psi, true, tap ? tap + D : nullptr, vgt_ln1, fnext, &vgt_ln1);
     if (st) return st;
     if (is_tap) {
       if (out->taps[tap_i]) LCHK(c, hipMemcpyAsync(out->taps[tap_i], tap, (size_t)d.Mv * 2 * D * 4, hipMemcpyDeviceToDevice, s));
@@ -1531,6 +1572,22 @@ extern "C" wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* W
   if (wm_tuning[WM_TUNE_OP_LDPAD] > 0) a.lda = a.ldw = K + wm_tuning[WM_TUNE_OP_LDPAD];  // wm_op_gemm only: operand row pitch (elements)
   a.dtype = dtype; a.epi = epi;
   return wm_launch_gemm(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_gemm_resid_ln(int dtype, const void* A, const void* Wp, float* X, const float* bias, const float* gamma, const float* ln_w,
+                                         const float* ln_b, float ln_eps, void* ln_out, float* stats, int* sync, int M, int N, int K, int* fused_out,
+                                         void* stream) {
+  WmGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.W = Wp; a.C = X; a.bias = bias; a.gamma = gamma; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N;
+  a.dtype = dtype; a.epi = WM_EPI_RESID;
+  a.ln_out = ln_out; a.ln_ld = N; a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps; a.ln_stats = stats; a.ln_sync = sync;
+  a.ln_fallback = sync + ((size_t)M / 16 + 2) * 2;
+  const bool fuse = wm_gemm_fuses_ln(a);
+  if (fused_out) *fused_out = fuse ? 1 : 0;
+  if (!fuse) a.ln_out = nullptr;
+  if (wm_launch_gemm(a, (hipStream_t)stream) != hipSuccess) return WM_ERR_HIP;
+  if (fuse && wm_launch_gemm_ln_fallback(a, (hipStream_t)stream) != hipSuccess) return WM_ERR_HIP;
+  return WM_OK;
 }
 extern "C" wm_status wm_op_gemm_qkv(int dtype, const void* A, const void* Wp, const float* bias, void* q, void* k, void* v,
                                     const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, const float* rope_cos,

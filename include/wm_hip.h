@@ -140,6 +140,13 @@ wm_status wm_op_gemm(int dtype, int epi, const void* A, const void* W, void* C, 
 wm_status wm_op_gemm_qkv(int dtype, const void* A, const void* W, const float* bias, void* q, void* k, void* v, const float* qn_w,
                          const float* qn_b, const float* kn_w, const float* kn_b, const float* rope_cos, const float* rope_sin, int M,
                          int H, int K, int tokens_per_view, int patch_start, int grid_w, float q_scale, void* stream);
+/* X[M][1024] += gamma * (A W^T + bias) with the FOLLOWING LayerNorm fused into the epilogue (round 4: block.py:44,61 behind :90-92;
+   mlp.py:29-35 / attention.py:67): ln_out[M][1024] (16-bit, the operand type) = LayerNorm(X_new) * ln_w + ln_b.  stats: M * 8 floats of
+   scratch; sync: 3 * (M / 16 + 2) ints, zero before the first call (the kernels leave them zero).  *fused_out tells whether the launch
+   took the fused epilogue (N = 1024, every block resident at once); if not, X is updated and ln_out is left untouched. */
+wm_status wm_op_gemm_resid_ln(int dtype, const void* A, const void* W, float* X, const float* bias, const float* gamma, const float* ln_w,
+                              const float* ln_b, float ln_eps, void* ln_out, float* stats, int* sync, int M, int N, int K, int* fused_out,
+                              void* stream);
 /* Q must be pre-scaled by log2(e)/sqrt(64) (what wm_op_qkv_post does with q_scale): softmax is evaluated in base 2 */
 wm_status wm_op_attention(int dtype, const void* Q, const void* K, const void* V, void* O, int H, int q_rows, int seq_len,
                           int kv_chunks, int kv_rows_per_chunk, void* stream);

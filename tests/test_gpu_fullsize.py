@@ -89,6 +89,34 @@ def test_c2_single_queue_forward_is_bit_identical_to_the_default(model_and_out):
         L.wm_set_tuning(b"heads_concurrent", -1)
 
 
+def test_c2_forward_with_fused_layernorm_epilogues(model_and_out):
+    """The opt-in fused form (tuning ln_fuse = 1): every residual GEMM of the backbone computes the LayerNorm that follows it in its
+    epilogue (the four column tiles of a row band exchange per-row partial statistics inside the launch; 142 of the forward's 145 backbone
+    LayerNorm launches disappear).  Same recipe, other summation order inside the row statistics: the outputs equal the default
+    forward's at the decorrelation floor of the rounded arithmetic, and the fused forward repeats itself bit for bit (the rendezvous
+    must not leak timing into the result)."""
+    from hunyuanworld_mirror_amd import _lib
+    m, img, out = model_and_out
+    L = _lib.lib()
+    keys = ("pts3d", "depth", "normals", "camera_params", "pts3d_conf")
+    assert L.wm_set_tuning(b"ln_fuse", 1) == 0
+    try:
+        a = m({"img": img})
+        torch.cuda.synchronize()
+        for _ in range(3):
+            b = m({"img": img})
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(a[k], b[k]), k
+    finally:
+        L.wm_set_tuning(b"ln_fuse", -1)
+    for k in ("pts3d", "depth", "normals"):
+        assert torch.isfinite(a[k]).all(), k
+        e = rel_l2(a[k].cpu().numpy(), out[k].cpu().numpy())
+        print("fused LayerNorm epilogues vs default", k, f"{e:.2e}")
+        assert 0 < e < 2.5e-3, (k, e)   # > 0: the fused path really ran (it is not bit-identical to the two-pass LayerNorm kernel)
+
+
 def test_c2_view_permutation_equivariance(model_and_out):
     """Views 1..N-1 are exchangeable (only view 0 carries the reference-frame tokens,
     visual_transformer.py:397-416): swapping two of them swaps their outputs.  Not bitwise: the key order of the

@@ -153,6 +153,56 @@ def test_gemm_pingpong_v3_matches_v2_bitwise(dev, K, cfg):
             assert torch.equal(ge, refge), f"gelu differs: M={M} N={N} K={K} cfg={cfg} rep={rep}"
 
 
+@pytest.mark.parametrize("M,K", [(11008, 1024), (11008, 4096), (10992, 1024), (2752, 512), (1376 * 5 + 3, 256), (12288, 128)])
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_gemm_residual_with_fused_layernorm(dev, M, K, dt):
+    """X += gamma (A W^T + b) with the following LayerNorm fused into the epilogue (the four column tiles of a row band exchange per-row
+    (mean, M2) partials inside the launch; gemm.hip epilogue_resid_ln).  Checked: X bit-identical to the unfused epilogue; the LayerNorm
+    output against fp32 torch LayerNorm of THAT X at the 16-bit tolerance, and against the library's own LayerNorm kernel up to rounding
+    flips (partial-combined statistics instead of a two-pass row: a few outputs differ by one ulp); several launches back to back on the
+    same buffers (the counters must come back to zero), ragged row counts, both tile schedules."""
+    N = 1024
+    g = torch.Generator(device="cpu").manual_seed(M + K + dt)
+    A = _t16(torch.randn(M, K, generator=g), dt).to(dev)
+    W = _t16(torch.randn(N, K, generator=g) / math.sqrt(K), dt).to(dev)
+    bias = torch.randn(N, generator=g).to(dev); gamma = (torch.randn(N, generator=g) * 0.3).to(dev)
+    lw = torch.randn(N, generator=g).to(dev); lb = torch.randn(N, generator=g).to(dev)
+    X0 = (torch.randn(M, N, generator=g) * 2 + 0.5).to(dev)
+    X0[:, 7] += 40.0    # a massive-activation channel: the row statistics must not lose the rest against it
+    L = _lib()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Xref = X0.clone()
+    assert L.wm_op_gemm(dt, 3, _p(A), _p(W), _p(Xref), _p(bias), _p(gamma), M, N, K, s) == 0
+    ln_ref16 = torch.empty(M, N, device=dev, dtype=torch.int16)
+    assert L.wm_op_layernorm(_p(Xref), _p(ln_ref16), _p(lw), _p(lb), M, N, 1e-5, 0, dt, s) == 0
+    stats = torch.empty(M * 8, device=dev); sync = torch.zeros(3 * (M // 16 + 2), device=dev, dtype=torch.int32)
+    fused = C.c_int(-1)
+    for sched in (-1, 0):
+        assert L.wm_set_tuning(b"gemm_sched", sched) == 0 and L.wm_set_tuning(b"ln_fuse", 1) == 0   # (the fused epilogue is opt-in: gemm.hip wm_gemm_fuses_ln)
+        try:
+            for rep in range(3):
+                X = X0.clone()
+                out16 = torch.full((M, N), 0x7FC0 if dt == BF16 else 0x7E00, device=dev, dtype=torch.int16)
+                assert L.wm_op_gemm_resid_ln(dt, _p(A), _p(W), _p(X), _p(bias), _p(gamma), _p(lw), _p(lb), 1e-5, _p(out16), _p(stats), _p(sync), M, N, K,
+                                             C.byref(fused), s) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(X, Xref), "residual stream differs from the unfused epilogue"
+                if fused.value != 1:      # shapes the launcher keeps on another tile configuration: X only, ln_out untouched
+                    assert M < 10000, "the 8-view backbone shapes must take the fused epilogue"
+                    e, diff = float("nan"), float("nan")
+                    continue
+                assert int(sync.abs().sum()) == 0, "rendezvous counters / fallback flags not back at zero"
+                got = _from16(out16, dt)
+                ref = torch.nn.functional.layer_norm(Xref, (N,), lw, lb, 1e-5)
+                e = _rel(got, ref)
+                diff = float((out16 != ln_ref16).float().mean())
+                assert torch.isfinite(got).all() and e < (4e-3 if dt == BF16 else 6e-4), e
+                assert diff < 0.01, f"{100 * diff:.2f} % of the outputs differ from the LayerNorm kernel's"
+        finally:
+            L.wm_set_tuning(b"gemm_sched", -1); L.wm_set_tuning(b"ln_fuse", -1)
+    print(f"fused LN M{M} K{K} dt{dt}: rel-L2 vs torch {e:.2e}, {100 * diff:.3f} % of the 16-bit outputs differ from the LayerNorm kernel")
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed C-write (guides §3)."""
     K = N = 128
