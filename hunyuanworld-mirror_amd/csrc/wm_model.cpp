@@ -444,7 +444,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -1444,21 +1444,39 @@ wm_status forward_impl(wm_handle* h, const float* img, int n, int first_view, in
       if (out->splat_means && !(cf.enable_cam && out->camera_params)) return fail(h, WM_ERR_INVALID, "splats need the camera head");
       jobs.push_back({"gs_head.", cf.gs_dim, 2, WM_ACT_EXP, true, out->gs_depth, out->gs_depth_conf});
     }
-    for (size_t k = 0; k < jobs.size(); ++k) {
+    // Round 4: the LAST head runs on the caller's stream itself and only the others fork.  HIP multiplexes streams onto four hardware
+    // queues: with every head on a stream of its own (three heads + the camera head + the caller's idle stream) two DPT heads shared
+    // a hardware queue and ran one after the other — the kernel trace of a timed forward showed one head done after 7.5 ms and the other
+    // two, serialised, after 12.3 ms (profiles/r04_head_phase_queues.md).  Side heads are enqueued first, the caller's stream joins them
+    // only behind its own head's launches.
+    const size_t main_k = jobs.empty() || wm_tuning[WM_TUNE_HEADS_MAIN] == 0 ? (size_t)-1 : jobs.size() - 1;   // (tuning heads_main = 0: every head forks, round 3's form — A/B)
+    auto run_head = [&](size_t k, hipStream_t hs) -> wm_status {
       Ctx hc = c;
-      if (!serial && (jobs.size() > 1 || cam_async)) {
+      hc.s = hs;
+      if (jobs[k].gs && cam_async) LCHK(c, hipStreamWaitEvent(hs, h->camjoin, 0));  // the splats are unprojected with the predicted cameras
+      return dpt_head(hc, jobs[k].p, jobs[k].F, jobs[k].od, jobs[k].act, jobs[k].gs, jobs[k].attr, jobs[k].conf, img, out, first_view, (int)k);
+    };
+    const bool fork_heads = !serial && (jobs.size() > 1 || cam_async);
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      if (fork_heads && k == main_k) continue;
+      hipStream_t hs = s;
+      if (fork_heads) {
         if (!h->hstream[k]) LCHK(c, hipStreamCreateWithFlags(&h->hstream[k], hipStreamNonBlocking));
         if (!h->hjoin[k]) LCHK(c, hipEventCreateWithFlags(&h->hjoin[k], hipEventDisableTiming));
-        hc.s = h->hstream[k];
-        LCHK(c, hipStreamWaitEvent(hc.s, h->hfork, 0));
+        hs = h->hstream[k];
+        LCHK(c, hipStreamWaitEvent(hs, h->hfork, 0));
       }
-      if (jobs[k].gs && cam_async) LCHK(c, hipStreamWaitEvent(hc.s, h->camjoin, 0));  // the splats are unprojected with the predicted cameras
-      st = dpt_head(hc, jobs[k].p, jobs[k].F, jobs[k].od, jobs[k].act, jobs[k].gs, jobs[k].attr, jobs[k].conf, img, out, first_view, (int)k);
+      st = run_head(k, hs);
       if (st) return st;
-      if (hc.s != s) {
-        LCHK(c, hipEventRecord(h->hjoin[k], hc.s));
-        LCHK(c, hipStreamWaitEvent(s, h->hjoin[k], 0));
+      if (hs != s) LCHK(c, hipEventRecord(h->hjoin[k], hs));
+    }
+    if (fork_heads && !jobs.empty()) {
+      if (main_k != (size_t)-1) {
+        st = run_head(main_k, s);
+        if (st) return st;
       }
+      for (size_t k = 0; k < jobs.size(); ++k)
+        if (k != main_k) LCHK(c, hipStreamWaitEvent(s, h->hjoin[k], 0));
     }
   }
   if (cam_async) LCHK(c, hipStreamWaitEvent(s, h->camjoin, 0));
