@@ -754,7 +754,7 @@ wm_status comm_allgather(wm_handle* h, const void* send, void* recv, size_t byte
   ProfScope ps(h, 12, s);   // timing kind 12: the collective, on the queue it runs on (the compute queue unless WM_COMM_OVERLAP=1)
   Comm& cm = h->comm;
   if (cm.kind == 1) {
-    if (wm_tuning[WM_TUNE_COMM_P2P] == 1 && cm.world > 1) {
+    if (wm_tuning[WM_TUNE_COMM_P2P] == 1) {
       // Direct all-gather (opt-in, tuning comm_p2p = 1 / bench.py --gather p2p): every rank sends its chunk to every peer and
       // receives every peer's chunk as ONE group of point-to-point operations, so each of the 7 xGMI links of a GPU carries one
       // chunk in each direction at once (~0.29 ms per layer link-bound at C4, against ~2.1 ms if the all-gather

@@ -192,6 +192,13 @@ torch.cuda.synchronize()
 e = rel_l2(out['pts3d'].cpu().numpy(), outs['pts3d'])
 print('rccl world-1 pts3d', e)
 assert e < 5e-3
+# the opt-in point-to-point form of the gather (bench.py --gather p2p): at world 1 the group of sends / receives is empty and the
+# rank's own chunk is a device copy -- same result bit for bit
+assert L.wm_set_tuning(b"comm_p2p", 1) == 0
+out2 = m({k: torch.from_numpy(v).cuda() for k, v in views.items()}, flags)
+torch.cuda.synchronize()
+assert torch.equal(out2['pts3d'], out['pts3d']) and torch.equal(out2['depth'], out['depth'])
+print('rccl world-1 p2p gather: bit-identical')
 """
     env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
