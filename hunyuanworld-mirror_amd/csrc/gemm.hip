@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -544,6 +544,63 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
             const float4 nv = make_float4(o.x + gm.x * (acc[i][j][0] + bs.x), o.y + gm.y * (acc[i][j][1] + bs.y), o.z + gm.z * (acc[i][j][2] + bs.z), o.w + gm.w * (acc[i][j][3] + bs.w));
             *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = nv;
             if (p.C2) *(float4*)(p.C2 + (size_t)row * p.ldc2 + col) = nv;  // tap half (block-uniform branch)
+          }
+        }
+      }
+      return;
+    }
+    if constexpr (EPI == WM_EPI_CONV) {
+      // y = acc + bias + relu?(resid) + resid2 (ResidualConvUnit skip and fusion add, dense_head.py:435-455), optional ReLU; fp32 NHWC, or
+      // 16-bit when the only consumer rounds to the operand type anyway.  The residuals of row group i + 1 are requested before row
+      // group i is stored (the output may alias neither).
+      float4 rs[2][SN], r2[2][SN];
+      auto load_res = [&](int i, float4 (&a)[SN], float4 (&b)[SN]) {
+        const int row = rowb + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < SN; ++j) {
+          const int col = colb + j * 16 + 4 * lq;
+          const bool ok = row < mlim && col < p.N;
+          a[j] = (p.cv_resid && ok) ? *(const float4*)(p.cv_resid + (size_t)row * p.ldc + col) : make_float4(0, 0, 0, 0);
+          b[j] = (p.cv_resid2 && ok) ? *(const float4*)(p.cv_resid2 + (size_t)row * p.ldc + col) : make_float4(0, 0, 0, 0);
+        }
+      };
+      load_res(0, rs[0], r2[0]);
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        if (rowb + i * 16 >= mlim) break;
+        if (i + 1 < SM) load_res(i + 1, rs[(i + 1) & 1], r2[(i + 1) & 1]);
+        const int row = rowb + i * 16 + l15;
+        float4 y[SN];
+#pragma unroll
+        for (int j = 0; j < SN; ++j) {
+          float4 a = rs[i & 1][j];
+          if (p.cv_resid_relu) a = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+          const float4 b = r2[i & 1][j], bs = bs4[j];
+          y[j] = make_float4(acc[i][j][0] + bs.x + a.x + b.x, acc[i][j][1] + bs.y + a.y + b.y, acc[i][j][2] + bs.z + a.z + b.z, acc[i][j][3] + bs.w + a.w + b.w);
+          if (p.relu) y[j] = make_float4(fmaxf(y[j].x, 0.f), fmaxf(y[j].y, 0.f), fmaxf(y[j].z, 0.f), fmaxf(y[j].w, 0.f));
+        }
+        if (p.out16) {
+          if constexpr (SN % 2 == 0) {
+#pragma unroll
+            for (int jp = 0; jp < SN / 2; ++jp) {
+              uint2 u[2];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const float4 x = y[2 * jp + h];
+                u[h].x = (uint32_t)f2t<T>(x.x) | ((uint32_t)f2t<T>(x.y) << 16);
+                u[h].y = (uint32_t)f2t<T>(x.z) | ((uint32_t)f2t<T>(x.w) << 16);
+              }
+              swap16(u[0].x, u[1].x);
+              swap16(u[0].y, u[1].y);
+              const int col = colb + (2 * jp + (lq & 1)) * 16 + 4 * (lq & 2);
+              if (row < mlim && col < p.N) *(uint4*)((u16*)p.C + (size_t)row * p.ldc + col) = make_uint4(u[0].x, u[0].y, u[1].x, u[1].y);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < SN; ++j) {
+            const int col = colb + j * 16 + 4 * lq;
+            if (row < mlim && col < p.N) *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = y[j];
           }
         }
       }
@@ -1077,6 +1134,11 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   // this wave's DMA pieces per K-tile, in issue order: A0 A0 B0 B0 | B1 B1 | A1 A1 (the second A piece only if `two`)
   const u16* gp[8];
   int loff[8];
+  // WM_EPI_CONV: the A rows are pixels; per A piece the lane's pixel, its border flags and its 16-B chunk, and (wave-uniform) the
+  // tap / channel chunk of the K-tile the piece is issued for next (K-tile kt = tap * chunks + chunk: the weight's own K order)
+  constexpr bool CONV = EPI == WM_EPI_CONV;
+  int cv_pix[4], cv_fl[4], cv_c8[4], cv_tap[4] = {0, 0, 0, 0}, cv_cc[4] = {0, 0, 0, 0};
+  const int cv_nch = CONV ? p.cv_cin >> 6 : 1;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const bool isA = i < 2 || i >= 6;
@@ -1096,12 +1158,34 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
     gr = gr < lim ? gr : lim;
     gp[i] = (isA ? (const u16*)p.A + (size_t)gr * p.lda : (const u16*)p.W + (size_t)gr * p.ldw) + c * 8;
     loff[i] = (isA ? 0 : A_BYTES) + pl * 1024;
+    if constexpr (CONV) {
+      if (isA) {   // the row is a pixel (n, y, x) of the NHWC input: remember it and which image borders it touches
+        const int ai = i < 2 ? i : i - 4;
+        const int hw = p.cv_h * p.cv_w, n = gr / hw, rem = gr - n * hw, y = rem / p.cv_w, x = rem - y * p.cv_w;
+        cv_pix[ai] = gr;
+        cv_fl[ai] = (y == 0 ? 1 : 0) | (y == p.cv_h - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == p.cv_w - 1 ? 8 : 0);
+        cv_c8[ai] = c * 8;
+      }
+    }
   }
   auto dma = [&](int buf, int i0, int i1, bool in_loop = false) {
     if ((DBG == 6 || (DBG >= 16 && (DBG & 1))) && in_loop) return;  // timing experiment: no LDS-DMA inside the K loop (the counted waits then never block)
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
       if ((i == 1 || i == 7) && !two) continue;  // wave-uniform
+      if constexpr (CONV) {
+        if (i < 2 || i >= 6) {   // an A piece: the pixel shifted by the K-tile's tap, or the zero page outside the image
+          const int ai = i < 2 ? i : i - 4;
+          const int tap = cv_tap[ai], cc = cv_cc[ai];
+          const int ty = tap / 3, dy = ty - 1, dx = tap - ty * 3 - 1;
+          const int mask = (dy < 0 ? 1 : 0) | (dy > 0 ? 2 : 0) | (dx < 0 ? 4 : 0) | (dx > 0 ? 8 : 0);   // wave-uniform
+          const u16* inside = (const u16*)p.A + ((long long)(cv_pix[ai] + dy * p.cv_w + dx) * p.cv_cin + cc * 64 + cv_c8[ai]);
+          const u16* src = (cv_fl[ai] & mask) ? (const u16*)p.cv_zero + cv_c8[ai] : inside;
+          __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(smem + buf * STAGE + loff[i]), 16, 0, 0);
+          if (++cv_cc[ai] == cv_nch) { cv_cc[ai] = 0; ++cv_tap[ai]; }
+          continue;
+        }
+      }
       __builtin_amdgcn_global_load_lds((glb_vp)gp[i], (lds_vp)(smem + buf * STAGE + loff[i]), 16, 0, 0);
       gp[i] += 64;
     }
@@ -1383,10 +1467,14 @@ template <int T, int EPI>
 hipError_t launch_pp_E(const WmGemmArgs& a, int cfg, hipStream_t s) {
   // gemm_pp tuning: 3 = v1, 4 = v3 (half the barriers: bit-identical, measured +0.1 - 0.3 % on the forward, i.e. nothing — kept
   // selectable and under test as the record of that experiment), anything else = v2 (a barrier on both sides of every MFMA stage)
-  const int ver = wm_tuning[WM_TUNE_GEMM_PP];
-  if (ver == 4) return cfg == 4 ? launch_pp2<T, EPI, 0, 4, 3>(a, s) : launch_pp2<T, EPI, 0, 3, 3>(a, s);
-  if (ver != 3) return cfg == 4 ? launch_pp2<T, EPI>(a, s) : launch_pp2<T, EPI, 0, 3>(a, s);
-  return cfg == 5 ? launch_pp<T, EPI, 3>(a, s) : launch_pp<T, EPI, 4>(a, s);
+  const int ver = EPI == WM_EPI_CONV ? 2 : wm_tuning[WM_TUNE_GEMM_PP];   // the pixel-row addressing of WM_EPI_CONV lives in v2 only
+  if constexpr (EPI == WM_EPI_CONV) {
+    return cfg == 4 ? launch_pp2<T, EPI>(a, s) : launch_pp2<T, EPI, 0, 3>(a, s);
+  } else {
+    if (ver == 4) return cfg == 4 ? launch_pp2<T, EPI, 0, 4, 3>(a, s) : launch_pp2<T, EPI, 0, 3, 3>(a, s);
+    if (ver != 3) return cfg == 4 ? launch_pp2<T, EPI>(a, s) : launch_pp2<T, EPI, 0, 3>(a, s);
+    return cfg == 5 ? launch_pp<T, EPI, 3>(a, s) : launch_pp<T, EPI, 4>(a, s);
+  }
 }
 
 // tile configurations: id -> (WM, WN, TM, TN, NSTAGE)
@@ -1432,6 +1520,7 @@ hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
   if (pp > 10 && a.epi == WM_EPI_F32 && T == WM_T_BF16)
     return pp == 11 ? launch_pp<T, WM_EPI_F32, 4, 1>(a, s) : pp == 12 ? launch_pp<T, WM_EPI_F32, 4, 2>(a, s) : launch_pp<T, WM_EPI_F32, 4, 3>(a, s);
 #endif
+  if (a.epi == WM_EPI_CONV) return cfg == 4 || cfg == 5 ? launch_pp_E<T, WM_EPI_CONV>(a, cfg, s) : hipErrorInvalidValue;   // the ping-pong v2 kernel only
   if (pp && (cfg == 4 || cfg == 5)) {
     switch (a.epi) {
       case WM_EPI_F32: return launch_pp_E<T, WM_EPI_F32>(a, cfg, s);
@@ -1466,9 +1555,10 @@ hipError_t launch_T(const WmGemmArgs& a, int cfg, hipStream_t s) {
 
 int pick_cfg(const WmGemmArgs& a) {
   static const int forced = [] { const char* e = wm_env("WM_GEMM_CFG"); return e ? atoi(e) : -1; }();
-  if (wm_tuning[WM_TUNE_GEMM_CFG] >= 0) return wm_tuning[WM_TUNE_GEMM_CFG];
-  if (forced >= 0) return forced;
-  if (a.M <= 128 || a.N <= 128) return 0;
+  const bool conv = a.epi == WM_EPI_CONV;   // lives in the ping-pong v2 kernel only: tile 4 or 5 whatever the size
+  if (wm_tuning[WM_TUNE_GEMM_CFG] >= 0 && (!conv || wm_tuning[WM_TUNE_GEMM_CFG] == 4 || wm_tuning[WM_TUNE_GEMM_CFG] == 5)) return wm_tuning[WM_TUNE_GEMM_CFG];
+  if (forced >= 0 && (!conv || forced == 4 || forced == 5)) return forced;
+  if (!conv && (a.M <= 128 || a.N <= 128)) return 0;
   // minimise (rounds over the CUs) x (tile area / relative tile efficiency): tile quantisation is the
   // first-order loss at M = 11008 (e.g. 516 tiles of 256^2 on 256 CUs = 3 rounds)
   static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
@@ -1478,6 +1568,7 @@ int pick_cfg(const WmGemmArgs& a) {
   int best = 4;
   float best_cost = 1e30f;
   for (const Cand& c : cands) {
+    if (conv && c.id != 4 && c.id != 5) continue;
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const long rounds = (tiles + (long)ncu * c.per_cu - 1) / ((long)ncu * c.per_cu);
     const float cost = (float)rounds * c.per_cu * c.bm * c.bn / c.eff;  // co-resident blocks share the CU
@@ -1569,7 +1660,7 @@ static void plan_gemm(const WmGemmArgs& a, int& cfg, int& sched_b, bool& pp2_out
     // ping-pong v2 launches only (launch_T): backbone epilogues on the 256- / 192-row tiles
     const int ncu = wm_ncu();
     const int pp = wm_tuning[WM_TUNE_GEMM_PP];
-    const bool pp2 = (cfg == 4 || cfg == 5) && (pp < 0 || pp == 1 || pp == 2 || pp == 4) && (a.epi == WM_EPI_F32 || a.epi == WM_EPI_T16 || a.epi == WM_EPI_GELU_T16 || a.epi == WM_EPI_RESID || a.epi == WM_EPI_QKV);
+    const bool pp2 = (cfg == 4 || cfg == 5) && (pp < 0 || pp == 1 || pp == 2 || pp == 4 || a.epi == WM_EPI_CONV) && (a.epi == WM_EPI_F32 || a.epi == WM_EPI_T16 || a.epi == WM_EPI_GELU_T16 || a.epi == WM_EPI_RESID || a.epi == WM_EPI_QKV || a.epi == WM_EPI_CONV);
     const int ts = wm_tuning[WM_TUNE_GEMM_SCHED];   // -1 choose, 0 off (full-height tiles), > 0 that many bands
     if (pp2 && ts != 0) {
       // Measured (profiles/r04_gemm_timeline.md, `sched` rows): at M = 11008 the schedule takes 2.4 - 5.1 % off all four backbone
@@ -1586,6 +1677,7 @@ static void plan_gemm(const WmGemmArgs& a, int& cfg, int& sched_b, bool& pp2_out
     pp2_out = pp2 && wm_tuning[WM_TUNE_GEMM_PP] != 0;
     static const int pp_env = [] { const char* e = wm_env("WM_GEMM_PP"); return e ? atoi(e) : 1; }();
     if (wm_tuning[WM_TUNE_GEMM_PP] < 0 && !pp_env) pp2_out = false;
+    if (a.epi == WM_EPI_CONV) pp2_out = true;
   }
 }
 
@@ -1596,6 +1688,7 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
   if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
   if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
+  if (a.epi == WM_EPI_CONV && (a.cv_h <= 0 || a.cv_w <= 0 || a.cv_cin % 64 || a.K != 9 * a.cv_cin || a.M % (a.cv_h * a.cv_w) || !a.cv_zero || (a.N & 7))) return hipErrorInvalidValue;
   int cfg, sched_b;
   bool is_pp2;
   plan_gemm(a, cfg, sched_b, is_pp2);

@@ -26,6 +26,7 @@ enum {
   WM_EPI_ROWMAP_ADD = 4,  // C f32 [row-remapped] (+)= acc + bias + add[row % rpg][col]
   WM_EPI_CONVT = 5,       // k==stride ConvTranspose2d pixel-shuffle scatter, NHWC f32 out
   WM_EPI_QKV = 6,         // N = 3*D: bias, per-head LayerNorm(64) on q/k, 2-D RoPE, q scale, 16-bit [H][M][64] q/k/v
+  WM_EPI_CONV = 7,        // 3x3 conv as a GEMM over (pixel rows) x (tap, channel) K (WmGemmArgs::cv_*): acc + bias + relu?(resid) + resid2, fp32 NHWC or 16-bit out
 };
 
 // qkv f32 [M][3*D] -> Q,K,V 16-bit [H][M][64] with optional per-head LayerNorm(64) and 2-D RoPE
@@ -52,6 +53,14 @@ struct WmGemmArgs {
   int rows_per_group, out_group, out_off, accumulate, out16, relu;  // WM_EPI_ROWMAP_ADD (out16: C is 16-bit, no accumulate; relu before add)
   int ct_k, ct_cout, ct_gh, ct_gw;                     // WM_EPI_CONVT
   WmQkvArgs qkv;                                       // WM_EPI_QKV (qkv.qkv unused; qkv.H*64 = D)
+  // WM_EPI_CONV (round 4): a 3x3 / stride 1 / pad 1 convolution of a 16-BIT NHWC tensor A = x[n][y][x][cv_cin] as the ping-pong GEMM itself:
+  // row r = pixel (n, y, x) in raster order, K-tile kt = (tap = kt / chunks, 64-channel chunk = kt % chunks), W = [Cout][tap][cin] (the conv
+  // weight layout: K-contiguous as it is).  The A piece of a K-tile is DMA-ed from the pixel shifted by the tap, or from cv_zero (>= 128 B of
+  // zeros) when that pixel lies outside the image: no im2col, no halo staging, no conversion pass.  M = N H W, K = 9 cv_cin, lda unused.
+  int cv_h, cv_w, cv_cin;                              // cv_h > 0 selects the mode
+  const void* cv_zero;
+  const float* cv_resid; const float* cv_resid2;       // fp32 [M][N] or null; cv_resid_relu: relu(resid) is added
+  int cv_resid_relu;                                   // (out16 / relu above: 16-bit output, ReLU on the result)
   // WM_EPI_RESID with the FOLLOWING LayerNorm fused into the epilogue (round 4; block.py:44,61 behind :90-92): when ln_out is set and
   // wm_gemm_fuses_ln(args) holds (N = 1024 = four column tiles, every block of the launch resident at once), the epilogue keeps the new
   // residual values in registers, the four column tiles of a row band exchange per-row (mean, M2) partials through ln_stats, and every
@@ -249,6 +258,6 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
                               const float* weights, int N, float voxel, float* o_means, float* o_quats, float* o_scales, float* o_opac,
                               float* o_sh, int* K_out, void* workspace, size_t ws_bytes, hipStream_t s);
 
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_CONV_GEMM, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

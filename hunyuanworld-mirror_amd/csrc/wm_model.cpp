@@ -444,7 +444,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main", "conv_gemm"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -1109,6 +1109,17 @@ wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, cons
   const bool pyr = ks == 3 && stride == 1 && up_hs == 0 && a.Cin == a.Cout && a.Cin >= 128;
   const int kind = up_hs > 0 ? 10 : pyr && Hi == 4 * c.d.gh ? 8 : pyr && Hi == 2 * c.d.gh ? 9 : 3;
   ProfScope ps(c.h, kind, c.s);
+  if (wm_tuning[WM_TUNE_CONV_GEMM] == 1 && in16 && ks == 3 && stride == 1 && pad == 1 && up_hs == 0 && a.Cin % 64 == 0 && a.Cout % 8 == 0 &&
+      (long)N * Hi * Wi >= 4096) {
+    // a 16-bit NHWC input: the conv IS the ping-pong GEMM over (pixels) x (tap, channel), the A pieces DMA-ed from the shifted pixels
+    WmGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.W = w->w16; g.C = y; g.bias = a.bias; g.M = N * Hi * Wi; g.N = a.Cout; g.K = 9 * a.Cin; g.lda = a.Cin; g.ldw = 9 * a.Cin; g.ldc = a.Cout;
+    g.dtype = c.hdt; g.epi = WM_EPI_CONV; g.cv_h = Hi; g.cv_w = Wi; g.cv_cin = a.Cin; g.cv_zero = B<uint16_t>(c.h, "ZERO256");
+    g.cv_resid = resid; g.cv_resid2 = resid2; g.cv_resid_relu = resid_relu ? 1 : 0; g.out16 = a.out16; g.relu = a.relu_out;
+    LCHK(c, wm_launch_gemm(g, c.s));
+    return WM_OK;
+  }
   LCHK(c, wm_launch_conv(a, c.s));
   return WM_OK;
 }
@@ -1774,6 +1785,29 @@ extern "C" wm_status wm_op_conv(int dtype, const float* x, const void* w16, cons
   a.ksize = ksize; a.stride = stride; a.pad = pad; a.Ho = (Hi + 2 * pad - ksize) / stride + 1; a.Wo = (Wi + 2 * pad - ksize) / stride + 1;
   a.relu_in = relu_in; a.resid_relu = resid_relu; a.dtype = dtype;
   return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+// wm_op_conv with the 16-bit tensor forms of the register-staged 3x3 kernel: x is 16-bit NHWC when in16 (relu_in must be 0), y is 16-bit NHWC
+// when out16 (refused with WM_ERR_INVALID when the launch would take a kernel without that form: wm_conv3x3_out16_ok)
+extern "C" wm_status wm_op_conv_ex(int dtype, const void* x, int in16, const void* w16, const float* bias, const float* resid, const float* resid2,
+                                   void* y, int out16, int N, int Hi, int Wi, int Cin, int Cout, int relu_in, int resid_relu, int relu_out, void* stream) {
+  WmConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const float*)x; a.w = w16; a.bias = bias; a.resid = resid; a.resid2 = resid2; a.y = (float*)y; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout;
+  a.ksize = 3; a.stride = 1; a.pad = 1; a.Ho = Hi; a.Wo = Wi; a.relu_in = relu_in; a.resid_relu = resid_relu; a.relu_out = relu_out; a.dtype = dtype;
+  a.in16 = in16; a.out16 = out16;
+  if ((in16 || out16) && !wm_conv3x3_out16_ok(a)) return WM_ERR_INVALID;
+  return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_conv3x3_gemm16(int dtype, const void* x16, const void* w16, const float* bias, const float* resid, int resid_relu,
+                                          const float* resid2, void* y, int out16, int relu_out, int N, int H, int W, int Cin, int Cout,
+                                          const void* zero16, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || (Cout & 7) || !zero16 || !x16 || !w16 || !y) return WM_ERR_INVALID;
+  WmGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = x16; g.W = w16; g.C = y; g.bias = bias; g.M = N * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldw = 9 * Cin; g.ldc = Cout;
+  g.dtype = dtype; g.epi = WM_EPI_CONV; g.cv_h = H; g.cv_w = W; g.cv_cin = Cin; g.cv_zero = zero16;
+  g.cv_resid = resid; g.cv_resid2 = resid2; g.cv_resid_relu = resid_relu; g.out16 = out16; g.relu = relu_out;
+  return wm_launch_gemm(g, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
 extern "C" wm_status wm_op_conv3x3_up(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi, int Wi,
                                       int Cin, int Cout, const float* addx, const float* addy, void* stream) {

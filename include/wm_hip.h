@@ -217,6 +217,20 @@ wm_status wm_confidence_mask(const float* conf, size_t n, float conf_threshold_p
 wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w16, const float* bias, float* y, int N, int Hs, int Ws, int Hi,
                             int Wi, int Cin, const float* addx, const float* addy, int relu_out, void* up16, void* stream);
 
+/* Operator-level entry (parity tests / A-B): wm_op_conv's 3x3 / stride 1 / pad 1 case with the 16-bit tensor forms the DPT heads use
+ * between their convs (dense_head.py:435-455): x is a 16-bit NHWC tensor of the operand type when in16 (relu_in must be 0: the producer
+ * applied it), y is one when out16 (+ ReLU when relu_out).  WM_ERR_INVALID when the shape's kernel has no such form. */
+wm_status wm_op_conv_ex(int dtype, const void* x, int in16, const void* w16, const float* bias, const float* resid, const float* resid2,
+                        void* y, int out16, int N, int Hi, int Wi, int Cin, int Cout, int relu_in, int resid_relu, int relu_out, void* stream);
+
+/* Operator-level entry (parity tests / A-B): Conv2d(Cin, Cout, 3, padding=1) on a 16-BIT NHWC tensor x16 [N][H][W][Cin] of the operand
+ * type, run as the ping-pong GEMM itself (rows = pixels, K = (tap, channel); no im2col): y = conv(x16) + bias + relu?(resid) + resid2,
+ * optional ReLU; y is fp32 NHWC, or 16-bit NHWC when out16.  The form the ResidualConvUnit's second conv takes (dense_head.py:435-455)
+ * when tuning "conv_gemm" = 1.  zero16: >= 128 B of device zeros.  Cin % 64 == 0, Cout % 8 == 0. */
+wm_status wm_op_conv3x3_gemm16(int dtype, const void* x16, const void* w16, const float* bias, const float* resid, int resid_relu,
+                               const float* resid2, void* y, int out16, int relu_out, int N, int H, int W, int Cin, int Cout,
+                               const void* zero16, void* stream);
+
 /* Voxel merge of the per-pixel splats — GaussianSplatRenderer.prune_gs (src/models/models/rasterization.py:301-387; called at
  * :216 and on predictions["splats"] by the callers).  Inputs [n, ...] device fp32: means [n,3], quats [n,4], scales [n,3],
  * opacities [n] (not read: the merged opacity is sum w^2 / sum w, as in the reference), sh [n,3] (degree-0 coefficients), weights [n].

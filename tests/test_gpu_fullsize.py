@@ -117,6 +117,34 @@ def test_c2_forward_with_fused_layernorm_epilogues(model_and_out):
         assert 0 < e < 2.5e-3, (k, e)   # > 0: the fused path really ran (it is not bit-identical to the two-pass LayerNorm kernel)
 
 
+def test_c2_forward_with_rcu_conv2_as_pingpong_gemm(model_and_out):
+    """The opt-in GEMM form of the ResidualConvUnits' second convs (tuning conv_gemm = 1: their 16-bit NHWC input goes through the
+    ping-pong GEMM kernel with tap-shifted LDS-DMA instead of the register-staged halo kernel; dense_head.py:435-455).  Same operands,
+    same fp32 epilogue, other accumulation order inside the K loop: the heads' outputs equal the default forward's at the rounding floor
+    of the 16-bit intermediates (the backbone is untouched: camera_params bit-identical), and the forward repeats itself bit for bit."""
+    from hunyuanworld_mirror_amd import _lib
+    m, img, out = model_and_out
+    L = _lib.lib()
+    assert L.wm_set_tuning(b"conv_gemm", 1) == 0
+    try:
+        a = m({"img": img})
+        torch.cuda.synchronize()
+        b = m({"img": img})
+        torch.cuda.synchronize()
+    finally:
+        L.wm_set_tuning(b"conv_gemm", -1)
+    assert torch.equal(a["camera_params"], out["camera_params"])
+    for k in ("pts3d", "depth", "normals", "pts3d_conf"):
+        assert torch.equal(a[k], b[k]), k
+        assert torch.isfinite(a[k]).all(), k
+        e = rel_l2(a[k].cpu().numpy(), out[k].cpu().numpy())
+        print("RCU conv2 as GEMM vs default", k, f"{e:.2e}")
+        # > 0: the GEMM form really ran.  This fixture's weights are the sensitivity-maximising preset: a flipped rounding of a 16-bit RCU
+        # intermediate decorrelates what follows (measured 4.3e-4 on pts3d; the fused-LayerNorm form sits at the same kind of floor).  Against
+        # the reference's goldens the form scores what the default scores (tools/pytest_with_tuning.py conv_gemm=1 tests/test_gpu_e2e.py: 3.18e-4)
+        assert 0 < e < 1.5e-3, (k, e)
+
+
 def test_c2_view_permutation_equivariance(model_and_out):
     """Views 1..N-1 are exchangeable (only view 0 carries the reference-frame tokens,
     visual_transformer.py:397-416): swapping two of them swaps their outputs.  Not bitwise: the key order of the

@@ -976,6 +976,55 @@ def test_up_conv_n32_unfused(dev, N, Hs, Ws, Hi, Wi, Cin):
         assert torch.equal(again, y2)
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("N,Hh,Ww,Cin,Cout", [(2, 37, 37, 256, 256), (1, 64, 64, 256, 256), (3, 20, 16, 64, 64), (2, 74, 74, 256, 256),
+                                              (1, 33, 40, 128, 256), (2, 148, 148, 256, 256), (1, 18, 14, 256, 128)])
+def test_conv3x3_as_pingpong_gemm_on_16bit_input(dev, dt, N, Hh, Ww, Cin, Cout):
+    """wm_op_conv3x3_gemm16: the 3x3 conv of a 16-bit NHWC tensor as the ping-pong GEMM itself (rows = pixels, K = (tap, channel), the A
+    pieces DMA-ed from the tap-shifted pixel or the zero page) — against fp32 torch on the same rounded operands: plain, with the
+    ResidualConvUnit's relu(resid) + fusion add (dense_head.py:435-455), with ReLU and a 16-bit output; ragged last row band, images
+    narrower than a tile row, several images per tile, row-band schedule on and off (bit-identical), bit-exact repeat."""
+    g = torch.Generator().manual_seed(N * 1000 + Hh + Cin + dt)
+    x16 = _t16(torch.randn(N, Hh, Ww, Cin, generator=g), dt).to(dev)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(9 * Cin)
+    w16 = _t16(w, dt).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    resid = torch.randn(N, Hh, Ww, Cout, generator=g).to(dev)
+    resid2 = torch.randn(N, Hh, Ww, Cout, generator=g).to(dev)
+    zero = torch.zeros(128, dtype=torch.int16, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xf, wf = x16.float(), w16.float()
+    base = torch.nn.functional.conv2d(xf.permute(0, 3, 1, 2), wf.permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    L_ = _lib()
+    for use_res, relu_out, out16 in ((False, 0, 0), (True, 0, 0), (False, 1, 1), (True, 1, 0)):
+        ref = base + (torch.relu(resid) + resid2 if use_res else 0)
+        if relu_out:
+            ref = torch.relu(ref)
+        outs = []
+        for sched in (1, 0, 1):
+            L_.wm_set_tuning(b"gemm_sched", sched)
+            try:
+                y = torch.full((N, Hh, Ww, Cout), float("nan"), device=dev) if not out16 else torch.full((N, Hh, Ww, Cout), -1, dtype=torch.int16, device=dev)
+                st = L_.wm_op_conv3x3_gemm16(dt, _p(x16), _p(w16), _p(b), _p(resid) if use_res else None, 1, _p(resid2) if use_res else None, _p(y),
+                                             out16, relu_out, N, Hh, Ww, Cin, Cout, _p(zero), s)
+                assert st == 0
+                torch.cuda.synchronize()
+            finally:
+                L_.wm_set_tuning(b"gemm_sched", -1)
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        y = outs[0]
+        if out16:
+            y = _from16(y, dt)
+            tol = 2e-3 if dt == F16 else 8e-3
+        else:
+            tol = 2e-5
+        assert torch.isfinite(y).all()
+        e = _rel(y, ref)
+        print(f"conv-gemm {N}x{Hh}x{Ww} {Cin}->{Cout} dt{dt} res{use_res} relu{relu_out} o16 {out16}: {e:.2e}")
+        assert e < tol, e
+
+
 @pytest.mark.parametrize("Cin,Cout,Hs,Ws,Hi,Wi,pos", [(256, 128, 20, 16, 40, 32, False), (128, 32, 40, 32, 70, 56, True),
                                                     (64, 64, 9, 11, 33, 40, True), (256, 128, 148, 148, 296, 296, False)])
 def test_conv3x3_fused_upsample(dev, Cin, Cout, Hs, Ws, Hi, Wi, pos):
