@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -1324,6 +1324,29 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
     if (!NO_BAR) __builtin_amdgcn_s_barrier();
   };
 
+  // WM_EPI_RESID (p.pf_c): the epilogue's read-modify-write of the fp32 residual tile is a burst every CU issues at the same moment
+  // (profiles/r04_gemm_ceiling.md: 11.9 us against 2 us for a plain epilogue).  In the last two K-tiles no refill is in flight: each lane
+  // then touches one 128-B line of the block's old C tile per instruction (QI instructions cover the 64 QI rows x 8 lines) with a 4-byte
+  // LDS-DMA into a scratch corner behind the ring — no destination register to keep alive, counted by vmcnt like the refills, never
+  // read — so that the epilogue's loads find the lines on their way or in the L2.  The waits behind it allow PF more operations.
+  constexpr bool PFX = EPI == WM_EPI_RESID && DBG == 0;
+  constexpr int PF = QI;
+  const bool do_pf = PFX && p.pf_c != 0 && nk >= 2;
+  auto prefetch_c = [&]() __attribute__((always_inline)) {
+    if constexpr (PFX) {
+      const int rows = 16 * S, last = (p.M - 1 - m0) < rows - 1 ? (p.M - 1 - m0) : rows - 1;
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int l = tid + 512 * j;
+        int row = l >> 3;
+        row = row < last ? row : last;
+        int col = n0 + (l & 7) * 32;
+        col = col < p.N - 1 ? col : p.N - 4;
+        const float* src = (const float*)p.C + (size_t)(m0 + row) * p.ldc + col;
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(smem + 2 * STAGE + wave * 256), 4, 0, 0);
+      }
+    }
+  };
   // The K loop, instantiated per number NB of 16-row units in this wave group's SECOND quadrant row (a shortened band drops
   // units from the end of the group): the choice is made once, outside the loop (a guard per MFMA group inside it measured
   // +30 % on the loop).  The first quadrant row is always whole (wm_launch_gemm keeps bands >= 4 QI - 4 units).
@@ -1346,7 +1369,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
       a[i][1] = *(const s16x8*)(tile + a_base + i * 2048 + foff1);
     }
     }
-    if (n1) WM_W2(10, 7); else WM_W2(2, 1);
+    if (n1) WM_W2(10, 7); else if (do_pf) WM_W2(2 + PF, 1 + PF); else WM_W2(2, 1);
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -1363,7 +1386,9 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
       b1[j][1] = *(const s16x8*)(tile + b_base + (2 + j) * 2048 + foff1);
     }
     }
-    if (n2) { dma(buf, 0, 4, true); WM_W2(12, 9); } else if (n1) WM_W2(8, 6); else wait_vmcnt<0>();
+    if (n2) { dma(buf, 0, 4, true); WM_W2(12, 9); }
+    else if (n1) { if (do_pf) { prefetch_c(); WM_W2(8 + PF, 6 + PF); } else WM_W2(8, 6); }
+    else if (do_pf) wait_vmcnt<PF>(); else wait_vmcnt<0>();
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -1390,7 +1415,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
         for (int j = 0; j < 2; ++j) acc[QI + i][2 + j] = mfma16<T>(b1[j][kh], a[i][kh], acc[QI + i][2 + j]);
     mfma_end();
     // ---- phase 3: quadrant (1,0) from registers; refill A1; next K-tile's {A0,B0} must have landed
-    if (n2) { dma(buf, 6, 8, true); WM_W2(12, 9); } else if (n1) WM_W2(4, 3);
+    if (n2) { dma(buf, 6, 8, true); WM_W2(12, 9); } else if (n1) { if (do_pf) WM_W2(4 + PF, 3 + PF); else WM_W2(4, 3); }
     stage_end();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -1438,7 +1463,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
 template <int T, int EPI, int DBG = 0, int QI = 4, int VER = 2>
 hipError_t launch_pp2(const WmGemmArgs& a, hipStream_t s) {
   constexpr int BM = 64 * QI;
-  constexpr size_t shm = (size_t)2 * (BM + 256) * 128;
+  constexpr size_t shm = (size_t)2 * (BM + 256) * 128 + (EPI == WM_EPI_RESID ? 2048 : 0);   // + the residual prefetch's scratch (8 waves x 256 B)
   const int ntn = (a.N + 255) / 256, ntm = a.sched_bands > 0 ? a.sched_bands : (a.M + BM - 1) / BM;
   static bool attr = false;
   if (!attr) {
@@ -1706,6 +1731,7 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   WmGemmArgs c = a;
   c.group_bands = gb;
   c.sched_bands = sched_b; c.sched_units = (a.M + 15) / 16;
+  c.pf_c = a.epi == WM_EPI_RESID && wm_tuning[WM_TUNE_RESID_PREFETCH] == 1 ? 1 : 0;
   if (!fuse_ln) c.ln_out = nullptr;   // the kernel takes the fused epilogue iff ln_out is set
   return c.dtype == WM_T_BF16 ? launch_T<WM_T_BF16>(c, cfg, s) : launch_T<WM_T_F16>(c, cfg, s);
 }

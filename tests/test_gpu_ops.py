@@ -153,6 +153,39 @@ def test_gemm_pingpong_v3_matches_v2_bitwise(dev, K, cfg):
             assert torch.equal(ge, refge), f"gelu differs: M={M} N={N} K={K} cfg={cfg} rep={rep}"
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 1024, 4096])
+@pytest.mark.parametrize("cfg", [4, 5])
+def test_gemm_residual_prefetch_is_bit_identical(dev, K, cfg):
+    """Tuning resid_prefetch = 1: the residual epilogue's old C tile is touched line by line during the last two K-tiles (4-byte LDS-DMA
+    into a scratch corner, counted by the same vmcnt as the operand refills — gemm.hip prefetch_c).  It moves no value: X must come out
+    bit-identical, from one K-tile (no prefetch window) up, on both tile heights, ragged row counts (rows past M clamp), scheduled bands."""
+    L = _lib()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for M, N in ((11008, 1024), (5000, 768), (1376 * 2 + 3, 256)):
+        g = torch.Generator(device="cpu").manual_seed(M + K + cfg)
+        A = _t16(torch.randn(M, K, generator=g), BF16).to(dev)
+        W = _t16(torch.randn(N, K, generator=g) / math.sqrt(K), BF16).to(dev)
+        bias = torch.randn(N, generator=g).to(dev); gamma = torch.randn(N, generator=g).to(dev)
+        X0 = torch.randn(M, N, generator=g).to(dev)
+        outs = {}
+        for pf in (0, 1):
+            assert L.wm_set_tuning(b"gemm_cfg", cfg) == 0 and L.wm_set_tuning(b"resid_prefetch", pf) == 0
+            try:
+                res = []
+                for rep in range(3 if pf else 1):
+                    X = X0.clone()
+                    assert L.wm_op_gemm(BF16, 3, _p(A), _p(W), _p(X), _p(bias), _p(gamma), M, N, K, s) == 0
+                    res.append(X)
+                torch.cuda.synchronize()
+                outs[pf] = res
+            finally:
+                L.wm_set_tuning(b"gemm_cfg", -1); L.wm_set_tuning(b"resid_prefetch", -1)
+        ref = outs[0][0]
+        assert _rel(ref, X0 + gamma * (A.float() @ W.float().t() + bias)) < 2e-5
+        for rep, X in enumerate(outs[1]):
+            assert torch.equal(X, ref), f"M={M} N={N} K={K} cfg={cfg} rep={rep}"
+
+
 @pytest.mark.parametrize("M,K", [(11008, 1024), (11008, 4096), (10992, 1024), (2752, 512), (1376 * 5 + 3, 256), (12288, 128)])
 @pytest.mark.parametrize("dt", [BF16, F16])
 def test_gemm_residual_with_fused_layernorm(dev, M, K, dt):
