@@ -222,6 +222,10 @@ hipError_t wm_launch_conv3x3_n32_in16(const WmConvN32Args& a, hipStream_t s);
 hipError_t wm_launch_bilinear16(const float* in, void* out16, int N, int Hi, int Wi, int Ho, int Wo, int C, const float* addx,
                                 const float* addy, int dtype, hipStream_t s);
 hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s);
+// conv3x3(bilinear resize(x)) as nine low-resolution 1x1 products + a bilinear gather (upconv.hip): the weight's tap-major copy, and the gather
+// over y16 [N][Hi][Wi][9][Co] (f16) -> out fp32 [N][Ho][Wo][Co] (+ bias); Co in {32, 64, 128}
+hipError_t wm_launch_repack_tap_major(const void* w16, void* wt16, int Co, int C, hipStream_t s);
+hipError_t wm_launch_upconv_gather(const void* y16, const float* bias, float* out, int N, int Hi, int Wi, int Ho, int Wo, int Co, hipStream_t s);
 
 // ------------------------------------------------------------------ camera head / small fp32 ops (small.hip)
 // Y[M][N] = act(X[M][K]) * W[N][K]^T + b ; all f32.  pre_act: 0 none, 1 SiLU on X.  post: 0 none, 1 SiLU, 2 GELU(erf)
@@ -259,6 +263,6 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
                               const float* weights, int N, float voxel, float* o_means, float* o_quats, float* o_scales, float* o_opac,
                               float* o_sh, int* K_out, void* workspace, size_t ws_bytes, hipStream_t s);
 
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_CONV_GEMM, WM_TUNE_RESID_PREFETCH, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_CONV_GEMM, WM_TUNE_RESID_PREFETCH, WM_TUNE_UP1_GATHER, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

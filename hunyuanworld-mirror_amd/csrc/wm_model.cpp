@@ -45,6 +45,7 @@ struct Weight {
   float* f32 = nullptr;  // device
   void* w16 = nullptr;   // device 16-bit repack
   int k16 = 0;           // padded K of the repack
+  bool tap_major = false;  // w16 holds a second copy [tap][Cout][Cin] of a 3x3 conv weight behind the first (numel elements in)
   std::vector<float> host;  // kept only for the few tensors the host needs (pos_embed, init_token)
   bool set = false;
   bool owned = true;  // false: device memory belongs to another handle (wm_share_weights)
@@ -444,7 +445,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main", "conv_gemm", "resid_prefetch"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main", "conv_gemm", "resid_prefetch", "up1_gather"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -516,7 +517,7 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
     if (w.f32) (void)hipFree(w.f32);
     if (w.w16) (void)hipFree(w.w16);
   }
-  w.f32 = nullptr; w.w16 = nullptr; w.owned = true;
+  w.f32 = nullptr; w.w16 = nullptr; w.owned = true; w.tap_major = false;
   w.shape = sh;
   w.set = true;
   const WKind k = classify(n, ndim);
@@ -545,6 +546,14 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
           for (int x = 0; x < kw; ++x)
             r[(((size_t)o * kh + y) * kw + x) * Ci + c] = h_to16(host[(((size_t)o * Ci + c) * kh + y) * kw + x], dt);
     w.k16 = kh * kw * Ci;
+    if (kh == 3 && kw == 3 && ends_with(n, "output_conv1.weight")) {
+      // a second, tap-major copy [tap][Cout][Cin] behind the first: the B operand of the low-resolution tap GEMM (upconv.hip)
+      r.resize(2 * numel);
+      for (int o = 0; o < Co; ++o)
+        for (int t = 0; t < 9; ++t)
+          for (int c = 0; c < Ci; ++c) r[numel + ((size_t)t * Co + o) * Ci + c] = r[((size_t)o * 9 + t) * Ci + c];
+      w.tap_major = true;
+    }
   } else {  // ConvTranspose2d [Cin][Cout][k][k] -> rows (i*k + j)*Cout + co, K = Cin
     const int Ci = (int)sh[0], Co = (int)sh[1], kk = (int)sh[2];
     r.resize(numel);
@@ -1141,11 +1150,12 @@ wm_status rcu(Ctx& c, const std::string& p, const float* x, const float* extra, 
 
 // FeatureFusionBlock.out_conv (1x1, dense_head.py:496) on x2 [N*H*W][F]: a plain GEMM when x2 came as a 16-bit tensor (the ping-pong
 // kernel, fp32 NHWC out), the generic conv kernel on the fp32 tensor otherwise
-wm_status out_conv(Ctx& c, const std::string& name, const float* x2, bool x2_is_16, float* y, int N, int Hh, int Ww, int F_) {
-  if (!x2_is_16) return conv(c, x2, name, true, nullptr, false, nullptr, y, N, Hh, Ww, 1, 1, 0, false);
+// y16: the output as a 16-bit tensor of the operand type (its only consumer is a GEMM: the tap GEMM of upconv.hip); needs x2_is_16
+wm_status out_conv(Ctx& c, const std::string& name, const float* x2, bool x2_is_16, float* y, int N, int Hh, int Ww, int F_, bool y16 = false) {
+  if (!x2_is_16) return y16 ? fail(c.h, WM_ERR_STATE, "out_conv: 16-bit output needs the 16-bit input") : conv(c, x2, name, true, nullptr, false, nullptr, y, N, Hh, Ww, 1, 1, 0, false);
   const Weight* w = W(c.h, name + ".weight");
   if (!w || !w->w16 || (int)w->shape[0] != F_ || (int)w->shape[1] != F_) return fail(c.h, WM_ERR_STATE, "missing conv weight " + name);
-  return gemm(c, c.hdt, WM_EPI_F32, x2, F_, w->w16, F_, y, F_, F(c.h, name + ".bias"), nullptr, N * Hh * Ww, F_, F_, nullptr, 3);
+  return gemm(c, c.hdt, y16 ? WM_EPI_T16 : WM_EPI_F32, x2, F_, w->w16, F_, y, F_, F(c.h, name + ".bias"), nullptr, N * Hh * Ww, F_, F_, nullptr, 3);
 }
 
 // DPTHead (dense_head.py:107-295) for views [v0, v0+n) of this rank
@@ -1215,6 +1225,11 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     const bool fuse_on = wm_tuning[WM_TUNE_CONV_FUSE_UP] != 0 && wm_env("WM_CONV_GENERIC") == nullptr;
     const bool fuse_up1 = fuse_on && F_ % 64 == 0 && 4 * Hs[0] * Ws[0] >= 256;
     const bool fuse_up2 = fuse_on && !is_gs && (F_ / 2) % 64 == 0;
+    // output_conv1 on the resized tensor as nine 1x1 products at the LOW resolution + a bilinear gather (upconv.hip): a quarter of the MFMA work
+    const Weight* w_oc1 = W(h, sc + "output_conv1.weight");
+    const bool gather_on = wm_tuning[WM_TUNE_UP1_GATHER] != 0 && c.hdt == WM_DT_F16 && w_oc1 && w_oc1->tap_major && F_ % 64 == 0 &&
+                           (int)w_oc1->shape[1] == F_ && ((int)w_oc1->shape[0] == 128 || (int)w_oc1->shape[0] == 64 || (int)w_oc1->shape[0] == 32);
+    bool up1_gather = false;
     for (int L = 2; L >= 0; --L) {  // refinenet3 (level 2), refinenet2 (level 1), refinenet1 (level 0)
       const std::string rp = sc + "refinenet" + std::to_string(L + 1) + ".";
       float* others[3];
@@ -1227,9 +1242,10 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       st = rcu(c, rp + "resConfUnit2.", others[1], nullptr, others[0], others[2], n, Hs[L], Ws[L], &x16);
       if (st) return st;
       const int Ho = L > 0 ? Hs[L - 1] : 2 * Hs[0], Wo = L > 0 ? Ws[L - 1] : 2 * Ws[0];
-      st = out_conv(c, rp + "out_conv", others[2], x16, others[0], n, Hs[L], Ws[L], F_);
+      up1_gather = L == 0 && gather_on && x16;
+      st = out_conv(c, rp + "out_conv", others[2], x16, others[0], n, Hs[L], Ws[L], F_, up1_gather);
       if (st) return st;
-      if (L == 0 && fuse_up1) { cur = others[0]; break; }  // the last resize is fused into output_conv1's input staging
+      if (L == 0 && (fuse_up1 || up1_gather)) { cur = others[0]; break; }  // the last resize is fused into output_conv1 (its input staging, or the tap form)
       LCHK(c, wm_launch_bilinear(others[0], others[1], n, Hs[L], Ws[L], Ho, Wo, F_, nullptr, nullptr, c.s));
       cur = others[1];
     }
@@ -1239,7 +1255,16 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       int k = 0;
       for (float* b : {S0, S1, S2, S3}) if (b != cur) others[k++] = b;
     }
-    if (fuse_up1) st = conv(c, cur, sc + "output_conv1", true, nullptr, false, nullptr, others[0], n, H8, W8, 3, 1, 1, false, Hs[0], Ws[0]);
+    if (up1_gather) {
+      const int Co = (int)w_oc1->shape[0];
+      const size_t numel = (size_t)Co * 9 * F_;
+      void* Y1 = others[1];
+      st = gemm(c, c.hdt, WM_EPI_T16, cur, F_, (const uint16_t*)w_oc1->w16 + numel, F_, Y1, 9 * Co, nullptr, nullptr, n * Hs[0] * Ws[0], 9 * Co, F_, nullptr, 10);
+      if (!st) {
+        ProfScope ps(h, 10, c.s);
+        LCHK(c, wm_launch_upconv_gather(Y1, F(h, sc + "output_conv1.bias"), others[0], n, Hs[0], Ws[0], H8, W8, Co, c.s));
+      }
+    } else if (fuse_up1) st = conv(c, cur, sc + "output_conv1", true, nullptr, false, nullptr, others[0], n, H8, W8, 3, 1, 1, false, Hs[0], Ws[0]);
     else st = conv(c, cur, sc + "output_conv1", true, nullptr, false, nullptr, others[0], n, H8, W8, 3, 1, 1, false);
     if (st) return st;
     const int Ho = gh * cf.patch_size, Wo = gw * cf.patch_size;
@@ -1797,6 +1822,22 @@ extern "C" wm_status wm_op_conv_ex(int dtype, const void* x, int in16, const voi
   a.in16 = in16; a.out16 = out16;
   if ((in16 || out16) && !wm_conv3x3_out16_ok(a)) return WM_ERR_INVALID;
   return wm_launch_conv(a, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+// Conv2d(C, Co, 3, padding=1)(F.interpolate(x, (Ho, Wo), bilinear, align_corners=True)) in the tap form of upconv.hip on a 16-bit (f16) NHWC x:
+// wt16: scratch of 9 Co C 16-bit elements (the tap-major weight copy), y16: scratch of N Hi Wi 9 Co 16-bit elements
+extern "C" wm_status wm_op_upconv3x3_tap(int dtype, const void* x16, const void* w16, const float* bias, float* out, int N, int Hi, int Wi, int Ho,
+                                         int Wo, int C, int Co, void* wt16, void* y16, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype != WM_DT_F16 || !x16 || !w16 || !out || !wt16 || !y16 || C % 64) return WM_ERR_INVALID;
+  if (wm_launch_repack_tap_major(w16, wt16, Co, C, s) != hipSuccess) return WM_ERR_HIP;
+  WmGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = x16; g.W = wt16; g.C = y16; g.M = N * Hi * Wi; g.N = 9 * Co; g.K = C; g.lda = C; g.ldw = C; g.ldc = 9 * Co; g.dtype = dtype; g.epi = WM_EPI_T16;
+  if (wm_launch_gemm(g, s) != hipSuccess) return WM_ERR_HIP;
+  return wm_launch_upconv_gather(y16, bias, out, N, Hi, Wi, Ho, Wo, Co, s) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+extern "C" wm_status wm_op_upconv_gather(const void* y16, const float* bias, float* out, int N, int Hi, int Wi, int Ho, int Wo, int Co, void* stream) {
+  return wm_launch_upconv_gather(y16, bias, out, N, Hi, Wi, Ho, Wo, Co, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
 extern "C" wm_status wm_op_conv3x3_gemm16(int dtype, const void* x16, const void* w16, const float* bias, const float* resid, int resid_relu,
                                           const float* resid2, void* y, int out16, int relu_out, int N, int H, int W, int Cin, int Cout,

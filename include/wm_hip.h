@@ -223,6 +223,14 @@ wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w16, const fl
 wm_status wm_op_conv_ex(int dtype, const void* x, int in16, const void* w16, const float* bias, const float* resid, const float* resid2,
                         void* y, int out16, int N, int Hi, int Wi, int Cin, int Cout, int relu_in, int resid_relu, int relu_out, void* stream);
 
+/* Operator-level entry (parity tests / A-B): Conv2d(C, Co, 3, padding=1)(F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=True)) —
+ * the DPT head's output_conv1 behind its last resize (dense_head.py:217-225,265-295) — in the tap form: the nine 1x1 products W_tap x at the
+ * LOW resolution (one GEMM, a quarter of the direct conv's flops) and a bilinear gather of them.  x16: f16 NHWC [N][Hi][Wi][C]; w16:
+ * [Co][3][3][C]; out: fp32 NHWC [N][Ho][Wo][Co]; wt16 / y16: caller-owned device scratch of 9*Co*C and N*Hi*Wi*9*Co 16-bit elements.
+ * dtype must be f16 (the products are stored in the operand type); C % 64 == 0; Co in {32, 64, 128}. */
+wm_status wm_op_upconv3x3_tap(int dtype, const void* x16, const void* w16, const float* bias, float* out, int N, int Hi, int Wi, int Ho,
+                              int Wo, int C, int Co, void* wt16, void* y16, void* stream);
+
 /* Operator-level entry (parity tests / A-B): Conv2d(Cin, Cout, 3, padding=1) on a 16-BIT NHWC tensor x16 [N][H][W][Cin] of the operand
  * type, run as the ping-pong GEMM itself (rows = pixels, K = (tap, channel); no im2col): y = conv(x16) + bias + relu?(resid) + resid2,
  * optional ReLU; y is fp32 NHWC, or 16-bit NHWC when out16.  The form the ResidualConvUnit's second conv takes (dense_head.py:435-455)

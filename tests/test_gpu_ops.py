@@ -1009,6 +1009,41 @@ def test_up_conv_n32_unfused(dev, N, Hs, Ws, Hi, Wi, Cin):
         assert torch.equal(again, y2)
 
 
+@pytest.mark.parametrize("N,Hi,Wi,Ho,Wo,Cin,Co", [(2, 20, 16, 40, 32, 256, 128), (1, 9, 11, 33, 40, 64, 64), (3, 37, 37, 74, 74, 256, 128),
+                                                  (1, 148, 148, 296, 296, 256, 128), (2, 12, 10, 12, 10, 128, 32), (1, 5, 7, 1, 1, 64, 32)])
+def test_upconv3x3_tap_form(dev, N, Hi, Wi, Ho, Wo, Cin, Co):
+    """wm_op_upconv3x3_tap: conv3x3(F.interpolate(x, align_corners=True)) as nine 1x1 products at the low resolution (one GEMM) + a bilinear
+    gather (upconv.hip; conv's channel mixing commutes with the per-channel interpolation) — against fp32 torch on the same f16 x and
+    weights (tolerance: the f16 rounding of the nine products), and against the fused-resize halo kernel the forward used before
+    (wm_op_conv3x3_up); zero padding at the high-resolution border, non-integer and identity scales, a 1x1 output, bit-exact repeat."""
+    g = torch.Generator().manual_seed(N * 100 + Hi + Cin + Co)
+    x = torch.randn(N, Hi, Wi, Cin, generator=g).half().to(dev)
+    w = (torch.randn(Co, 3, 3, Cin, generator=g) / math.sqrt(9 * Cin)).half().to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    out = torch.full((N, Ho, Wo, Co), float("nan"), device=dev)
+    wt = torch.empty(9 * Co * Cin, dtype=torch.int16, device=dev)
+    y16 = torch.empty(N * Hi * Wi * 9 * Co, dtype=torch.int16, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L_ = _lib()
+    assert L_.wm_op_upconv3x3_tap(F16, _p(x), _p(w), _p(b), _p(out), N, Hi, Wi, Ho, Wo, Cin, Co, _p(wt), _p(y16), s) == 0
+    torch.cuda.synchronize()
+    xr = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=True)
+    ref = torch.nn.functional.conv2d(xr, w.float().permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(out).all()
+    e = _rel(out, ref)
+    print(f"upconv tap form {N}x{Hi}x{Wi}->{Ho}x{Wo} {Cin}->{Co}: {e:.2e}")
+    assert e < 4e-4, e          # nine f16-rounded partial products per output (2^-11 each), fp32 everything else
+    if Hi * Wi >= 256 and Ho * Wo >= 256 and Co % 4 == 0:
+        y1 = torch.empty(N, Ho, Wo, Co, device=dev)
+        assert L_.wm_op_conv3x3_up(F16, _p(x.float()), _p(w), _p(b), _p(y1), N, Hi, Wi, Ho, Wo, Cin, Co, None, None, s) == 0
+        torch.cuda.synchronize()
+        assert _rel(out, y1) < 6e-4, _rel(out, y1)   # the halo kernel rounds the INTERPOLATED values to f16 instead
+    again = out.clone()
+    assert L_.wm_op_upconv3x3_tap(F16, _p(x), _p(w), _p(b), _p(out), N, Hi, Wi, Ho, Wo, Cin, Co, _p(wt), _p(y16), s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(again, out)
+
+
 @pytest.mark.parametrize("dt", [F16, BF16])
 @pytest.mark.parametrize("N,Hh,Ww,Cin,Cout", [(2, 37, 37, 256, 256), (1, 64, 64, 256, 256), (3, 20, 16, 64, 64), (2, 74, 74, 256, 256),
                                               (1, 33, 40, 128, 256), (2, 148, 148, 256, 256), (1, 18, 14, 256, 128)])

@@ -39,3 +39,24 @@ for (N, H, W, Cin, Cout) in [(8, 148, 148, 256, 256), (8, 74, 74, 256, 256)]:
         us = ts[len(ts) // 2]
         fl = 2.0 * N * H * W * Cout * 9 * Cin
         print(json.dumps({"shape": [N, H, W, Cin, Cout], "form": name, "us": round(us, 1), "tflops": round(fl / us / 1e6, 1)}), flush=True)
+
+# output_conv1 behind the last resize (148^2 -> 296^2, 256 -> 128): the fused-resize halo kernel vs the tap form (upconv.hip)
+N, Hi, Wi, Ho, Wo, Cin, Co = 8, 148, 148, 296, 296, 256, 128
+x = torch.randn(N, Hi, Wi, Cin, device=dev).half(); xf = x.float()
+w = (torch.randn(Co, 3, 3, Cin, device=dev) / math.sqrt(9 * Cin)).half(); b = torch.randn(Co, device=dev)
+out = torch.empty(N, Ho, Wo, Co, device=dev); wt = torch.empty(9 * Co * Cin, dtype=torch.int16, device=dev)
+y16 = torch.empty(N * Hi * Wi * 9 * Co, dtype=torch.int16, device=dev)
+for name, fn in (("up1_tap_form", lambda: L.wm_op_upconv3x3_tap(1, p(x), p(w), p(b), p(out), N, Hi, Wi, Ho, Wo, Cin, Co, p(wt), p(y16), s)),
+                 ("up1_fused_halo", lambda: L.wm_op_conv3x3_up(1, p(xf), p(w), p(b), p(out), N, Hi, Wi, Ho, Wo, Cin, Co, None, None, s))):
+    for _ in range(3):
+        assert fn() == 0
+    ts = []
+    for _ in range(9):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 5 * 1e3)
+    ts.sort()
+    print(json.dumps({"shape": [N, Hi, Wi, Ho, Wo, Cin, Co], "form": name, "us": round(ts[len(ts) // 2], 1)}), flush=True)
