@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int wm_tuning[WM_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 namespace {
 
@@ -553,6 +553,15 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
       // y = acc + bias + relu?(resid) + resid2 (ResidualConvUnit skip and fusion add, dense_head.py:435-455), optional ReLU; fp32 NHWC, or
       // 16-bit when the only consumer rounds to the operand type anyway.  The residuals of row group i + 1 are requested before row
       // group i is stored (the output may alias neither).
+      // token-conv form: row = token (n, i, j), this column tile = phase (a, b): the output row is pixel (k i + a, k j + b) and the tile's
+      // 256 columns are the channels (the ConvTranspose's depth-to-space, dense_head.py:57-66, composed with the 3x3 conv behind it)
+      auto out_row = [&](int row) -> size_t {
+        if (p.tc_k <= 0) return (size_t)row;
+        const int hw = p.cv_h * p.cv_w, n = row / hw, rem = row - n * hw, ti = rem / p.cv_w, tj = rem - ti * p.cv_w;
+        const int ph = colb / 256, a = ph / p.tc_k, b = ph - a * p.tc_k;
+        return ((size_t)(n * p.cv_h + ti) * p.tc_k + a) * (size_t)(p.cv_w * p.tc_k) + (size_t)(tj * p.tc_k + b);
+      };
+      const int cshift = p.tc_k > 0 ? (colb / 256) * 256 : 0;
       float4 rs[2][SN], r2[2][SN];
       auto load_res = [&](int i, float4 (&a)[SN], float4 (&b)[SN]) {
         const int row = rowb + i * 16 + l15;
@@ -593,14 +602,14 @@ __device__ __forceinline__ void epilogue16(const WmGemmArgs& p, f32x4 (&acc)[SM]
               swap16(u[0].x, u[1].x);
               swap16(u[0].y, u[1].y);
               const int col = colb + (2 * jp + (lq & 1)) * 16 + 4 * (lq & 2);
-              if (row < mlim && col < p.N) *(uint4*)((u16*)p.C + (size_t)row * p.ldc + col) = make_uint4(u[0].x, u[0].y, u[1].x, u[1].y);
+              if (row < mlim && col < p.N) *(uint4*)((u16*)p.C + out_row(row) * p.ldc + col - cshift) = make_uint4(u[0].x, u[0].y, u[1].x, u[1].y);
             }
           }
         } else {
 #pragma unroll
           for (int j = 0; j < SN; ++j) {
             const int col = colb + j * 16 + 4 * lq;
-            if (row < mlim && col < p.N) *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = y[j];
+            if (row < mlim && col < p.N) *(float4*)((float*)p.C + out_row(row) * p.ldc + col - cshift) = y[j];
           }
         }
       }
@@ -1139,6 +1148,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
   constexpr bool CONV = EPI == WM_EPI_CONV;
   int cv_pix[4], cv_fl[4], cv_c8[4], cv_tap[4] = {0, 0, 0, 0}, cv_cc[4] = {0, 0, 0, 0};
   const int cv_nch = CONV ? p.cv_cin >> 6 : 1;
+  // token-conv form (p.tc_k > 0): column tile nt is an output phase; its word = neighbour count << 16 | 4 bits (di + 1, dj + 1) per neighbour
+  const unsigned tc_word = CONV && p.tc_k > 0 ? p.tc_list[nt & 15] : 0u;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const bool isA = i < 2 || i >= 6;
@@ -1177,7 +1188,9 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
         if (i < 2 || i >= 6) {   // an A piece: the pixel shifted by the K-tile's tap, or the zero page outside the image
           const int ai = i < 2 ? i : i - 4;
           const int tap = cv_tap[ai], cc = cv_cc[ai];
-          const int ty = tap / 3, dy = ty - 1, dx = tap - ty * 3 - 1;
+          int dy, dx;
+          if (p.tc_k > 0) { const unsigned nb = tc_word >> (4 * tap); dy = (int)(nb & 3) - 1; dx = (int)((nb >> 2) & 3) - 1; }
+          else { const int ty = tap / 3; dy = ty - 1; dx = tap - ty * 3 - 1; }
           const int mask = (dy < 0 ? 1 : 0) | (dy > 0 ? 2 : 0) | (dx < 0 ? 4 : 0) | (dx > 0 ? 8 : 0);   // wave-uniform
           const u16* inside = (const u16*)p.A + ((long long)(cv_pix[ai] + dy * p.cv_w + dx) * p.cv_cin + cc * 64 + cv_c8[ai]);
           const u16* src = (cv_fl[ai] & mask) ? (const u16*)p.cv_zero + cv_c8[ai] : inside;
@@ -1205,7 +1218,8 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const WmGemmArgs p) {
     for (int j = 0; j < SN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   s16x8 a[QI][2], b0[2][2], b1[2][2];
 
-  const int nk = p.K / 64;
+  // (token-conv form of WM_EPI_CONV: this column tile's own neighbour list sets the K length)
+  const int nk = CONV && p.tc_k > 0 ? (int)(tc_word >> 16) * cv_nch : p.K / 64;
   dma(0, 0, 8);
   if (nk > 1) dma(1, 0, 8);
   if constexpr (VER == 3) {   // A0B0(0) and B1(0): group X reads B1(0) in the first interval, before group Y has had a wait of its own
@@ -1713,7 +1727,10 @@ hipError_t wm_launch_gemm(const WmGemmArgs& a, hipStream_t s) {
   if (a.epi == WM_EPI_CONVT && (a.ct_cout & 3)) return hipErrorInvalidValue;
   if (a.epi != WM_EPI_CONVT && a.epi != WM_EPI_QKV && (a.ldc & 3)) return hipErrorInvalidValue;
   if (a.epi == WM_EPI_QKV && (a.N % 64 || a.N != 3 * a.qkv.H * 64)) return hipErrorInvalidValue;
-  if (a.epi == WM_EPI_CONV && (a.cv_h <= 0 || a.cv_w <= 0 || a.cv_cin % 64 || a.K != 9 * a.cv_cin || a.M % (a.cv_h * a.cv_w) || !a.cv_zero || (a.N & 7))) return hipErrorInvalidValue;
+  if (a.epi == WM_EPI_CONV && a.tc_k <= 0 && (a.cv_h <= 0 || a.cv_w <= 0 || a.cv_cin % 64 || a.K != 9 * a.cv_cin || a.M % (a.cv_h * a.cv_w) || !a.cv_zero || (a.N & 7))) return hipErrorInvalidValue;
+  if (a.epi == WM_EPI_CONV && a.tc_k > 0 && (a.cv_h <= 0 || a.cv_w <= 0 || a.cv_cin % 64 || a.K != 4 * a.cv_cin || a.M % (a.cv_h * a.cv_w) || !a.cv_zero || a.tc_k > 4 ||
+                                             a.N != a.tc_k * a.tc_k * 256 || a.ldc != 256 || a.cv_resid || a.cv_resid2))
+    return hipErrorInvalidValue;
   int cfg, sched_b;
   bool is_pp2;
   plan_gemm(a, cfg, sched_b, is_pp2);

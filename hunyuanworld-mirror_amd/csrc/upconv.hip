@@ -208,7 +208,63 @@ __global__ __launch_bounds__(256) void upconv_gather_lds_kernel(const uint16_t* 
   }
 }
 
+// fp32 [rows][cols] (pitch ld_src) -> 16-bit [rows][cols] (pitch ld_dst): the combined token-conv matrices into their place in the B operand
+template <int T>
+__global__ __launch_bounds__(256) void f32_to_16_2d_kernel(const float* __restrict__ src, int ld_src, uint16_t* __restrict__ dst, int ld_dst, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+    dst[(size_t)r * ld_dst + c] = f2t<T>(src[(size_t)r * ld_src + c]);
+  }
+}
+
+// Token-conv border fix (gemm.hip, WM_EPI_CONV with tc_k > 0): the composed GEMM adds the ConvTranspose's bias through ALL nine taps of the 3x3
+// conv; on the image border the taps that fall outside see zero padding, not bias: subtract bmiss[tap][f] = (W_rn[tap] b_ct)[f] for those.
+__global__ __launch_bounds__(256) void tconv_border_kernel(float* __restrict__ out, const float* __restrict__ bmiss, int N, int H, int W, int F) {
+  const int per = 2 * W + 2 * (H - 2 > 0 ? H - 2 : 0), f4n = F / 4;
+  const size_t total = (size_t)N * per * f4n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int f = (int)(i % f4n) * 4;
+    size_t r = i / f4n;
+    const int b = (int)(r % per), n = (int)(r / per);
+    int Y, X;
+    if (b < W) { Y = 0; X = b; }
+    else if (b < 2 * W) { Y = H - 1; X = b - W; }
+    else { const int q = b - 2 * W; Y = 1 + (q >> 1); X = (q & 1) ? W - 1 : 0; }
+    if (H == 1 && b >= W) continue;          // a single row: its pixels are listed once
+    if (W == 1 && b >= 2 * W && (b & 1)) continue;
+    float4 sub = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        if (Y + dy >= 0 && Y + dy < H && X + dx >= 0 && X + dx < W) continue;
+        const float4 m = *(const float4*)(bmiss + (size_t)((dy + 1) * 3 + dx + 1) * F + f);
+        sub.x += m.x; sub.y += m.y; sub.z += m.z; sub.w += m.w;
+      }
+    float4* o = (float4*)(out + (((size_t)n * H + Y) * W + X) * F + f);
+    float4 v = *o;
+    v.x -= sub.x; v.y -= sub.y; v.z -= sub.z; v.w -= sub.w;
+    *o = v;
+  }
+}
+
 }  // namespace
+
+hipError_t wm_launch_f32_to_16_2d(const float* src, int ld_src, void* dst16, int ld_dst, int rows, int cols, int dtype, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  const size_t total = (size_t)rows * cols;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == WM_T_BF16) hipLaunchKernelGGL(f32_to_16_2d_kernel<WM_T_BF16>, dim3(grid), dim3(256), 0, s, src, ld_src, (uint16_t*)dst16, ld_dst, rows, cols);
+  else hipLaunchKernelGGL(f32_to_16_2d_kernel<WM_T_F16>, dim3(grid), dim3(256), 0, s, src, ld_src, (uint16_t*)dst16, ld_dst, rows, cols);
+  return hipGetLastError();
+}
+
+hipError_t wm_launch_tconv_border(float* out, const float* bmiss, int N, int H, int W, int F, hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || (F & 3)) return F & 3 ? hipErrorInvalidValue : hipSuccess;
+  const size_t total = (size_t)N * (2 * W + 2 * (H - 2 > 0 ? H - 2 : 0)) * (F / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(tconv_border_kernel, dim3(grid), dim3(256), 0, s, out, bmiss, N, H, W, F);
+  return hipGetLastError();
+}
 
 hipError_t wm_launch_repack_tap_major(const void* w16, void* wt16, int Co, int C, hipStream_t s) {
   if (Co <= 0 || C <= 0 || (C & 7)) return hipErrorInvalidValue;

@@ -62,6 +62,14 @@ struct WmGemmArgs {
   const void* cv_zero;
   const float* cv_resid; const float* cv_resid2;       // fp32 [M][N] or null; cv_resid_relu: relu(resid) is added
   int cv_resid_relu;                                   // (out16 / relu above: 16-bit output, ReLU on the result)
+  // Token-conv form of WM_EPI_CONV (tc_k > 0): Conv2d(3x3, pad 1, no bias) of ConvTranspose2d(kernel = stride = tc_k) of a token grid
+  // (dense_head.py:57-66 resize_layers[0 / 1] -> :394-399 layer{1,2}_rn) composed into one block-sparse GEMM at the TOKEN resolution: the A rows
+  // are tokens [n][cv_h][cv_w][cv_cin] (16-bit), column tile nt is the output phase (a, b) = (nt / tc_k, nt % tc_k) with N = tc_k^2 x 256 columns,
+  // and its K runs over that phase's own neighbour tokens only: tc_list[nt] = count << 16 | (di + 1 | (dj + 1) << 2) << 4 idx; W row (nt 256 + co)
+  // holds the phase's combined matrices (sum over the taps landing in a neighbour of W_rn[tap] W_ct[phase']) neighbour after neighbour (ldw = 4 cv_cin).
+  // Output: C[((n cv_h + i) tc_k + a) (cv_w tc_k) + j tc_k + b][co] (ldc = 256), bias = the interior bias repeated per phase.
+  int tc_k;
+  unsigned tc_list[16];
   // WM_EPI_RESID with the FOLLOWING LayerNorm fused into the epilogue (round 4; block.py:44,61 behind :90-92): when ln_out is set and
   // wm_gemm_fuses_ln(args) holds (N = 1024 = four column tiles, every block of the launch resident at once), the epilogue keeps the new
   // residual values in registers, the four column tiles of a row band exchange per-row (mean, M2) partials through ln_stats, and every
@@ -224,6 +232,9 @@ hipError_t wm_launch_bilinear16(const float* in, void* out16, int N, int Hi, int
 hipError_t wm_launch_conv(const WmConvArgs& a, hipStream_t s);
 // conv3x3(bilinear resize(x)) as nine low-resolution 1x1 products + a bilinear gather (upconv.hip): the weight's tap-major copy, and the gather
 // over y16 [N][Hi][Wi][9][Co] (f16) -> out fp32 [N][Ho][Wo][Co] (+ bias); Co in {32, 64, 128}
+hipError_t wm_launch_f32_to_16_2d(const float* src, int ld_src, void* dst16, int ld_dst, int rows, int cols, int dtype, hipStream_t s);
+// token-conv (WmGemmArgs::tc_k): subtract, on the image border, the ConvTranspose bias seen through the 3x3 taps that fall outside; bmiss [9][F]
+hipError_t wm_launch_tconv_border(float* out, const float* bmiss, int N, int H, int W, int F, hipStream_t s);
 hipError_t wm_launch_repack_tap_major(const void* w16, void* wt16, int Co, int C, hipStream_t s);
 hipError_t wm_launch_upconv_gather(const void* y16, const float* bias, float* out, int N, int Hi, int Wi, int Ho, int Wo, int Co, hipStream_t s);
 
@@ -263,6 +274,6 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
                               const float* weights, int N, float voxel, float* o_means, float* o_quats, float* o_scales, float* o_opac,
                               float* o_sh, int* K_out, void* workspace, size_t ws_bytes, hipStream_t s);
 
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_CONV_GEMM, WM_TUNE_RESID_PREFETCH, WM_TUNE_UP1_GATHER, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_CONV_GEMM, WM_TUNE_RESID_PREFETCH, WM_TUNE_UP1_GATHER, WM_TUNE_TCONV, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

@@ -51,6 +51,23 @@ struct Weight {
   bool owned = true;  // false: device memory belongs to another handle (wm_share_weights)
 };
 
+// the composed ConvTranspose -> 3x3 conv of a DPT head level (build_tconv below)
+struct TconvPack {
+  void* w16 = nullptr;        // [k^2 * 256][4 * Cin] 16-bit: row (phase, co), the phase's neighbour matrices side by side
+  float* bias_rep = nullptr;  // [k^2][256]: (sum_tap W_rn[tap]) b_ct, once per phase
+  float* bmiss = nullptr;     // [9][256]: W_rn[tap] b_ct (wm_launch_tconv_border)
+  unsigned list[16] = {0};
+  int k = 0, cin = 0;
+};
+static void free_tconv(TconvPack& t) {
+  if (t.w16) (void)hipFree(t.w16);
+  if (t.bias_rep) (void)hipFree(t.bias_rep);
+  if (t.bmiss) (void)hipFree(t.bmiss);
+  t = TconvPack();
+}
+
+static hipError_t build_tconv(int dt, int k, int Cin, int Cm, int F_, const float* wct, const float* bct, const float* wrn, TconvPack& out, hipStream_t s);
+
 struct EvPair { hipEvent_t a, b; };
 
 struct Comm {
@@ -81,6 +98,8 @@ struct wm_handle {
   size_t arena_bytes = 0;
   bool arena_owned = true;   // false: caller-provided (wm_set_workspace)
   int plan_n = -1, plan_nt = -1, plan_H = -1, plan_W = -1;
+  std::map<std::string, TconvPack> tconv;   // per head and level ("pts_head.0"): rebuilt by wm_reserve after a weight change
+  bool tconv_valid = false;
   std::vector<std::string> missing;  // names wm_finalize_weights filled with their init values
   // shape-dependent device tables (allocated inside the arena by plan())
   std::map<std::string, void*> buf;
@@ -445,7 +464,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main", "conv_gemm", "resid_prefetch", "up1_gather"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main", "conv_gemm", "resid_prefetch", "up1_gather", "tconv"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -472,6 +491,7 @@ extern "C" wm_status wm_create(const wm_config* cfg, int device, wm_handle** out
 extern "C" void wm_destroy(wm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  for (auto& kv : h->tconv) free_tconv(kv.second);
   for (auto& kv : h->w) {
     if (!kv.second.owned) continue;
     if (kv.second.f32) (void)hipFree(kv.second.f32);
@@ -513,6 +533,7 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
   for (auto s : sh) numel *= (size_t)s;
   Weight& w = h->w[n];
   h->plan_n = -1;  // weight-derived workspace tables (resampled pos_embed, camera init token) are rebuilt by the next wm_reserve
+  h->tconv_valid = false;
   if (w.owned) {
     if (w.f32) (void)hipFree(w.f32);
     if (w.w16) (void)hipFree(w.w16);
@@ -525,8 +546,13 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
     HIPCHK(h, hipMalloc((void**)&w.f32, std::max<size_t>(numel, 4) * 4));
     HIPCHK(h, hipMemcpy(w.f32, host, numel * 4, hipMemcpyHostToDevice));
     if (ends_with(n, "pos_embed") || ends_with(n, "init_token")) w.host.assign(host, host + numel);
+    if (n.find(".resize_layers.0.bias") != std::string::npos || n.find(".resize_layers.1.bias") != std::string::npos) w.host.assign(host, host + numel);
     return WM_OK;
   }
+  // the ConvTranspose / layer_rn pairs that wm_reserve composes into one token-resolution GEMM (build_tconv) are kept in fp32 on the host
+  if (n.find(".resize_layers.0.weight") != std::string::npos || n.find(".resize_layers.1.weight") != std::string::npos ||
+      ends_with(n, ".scratch.layer1_rn.weight") || ends_with(n, ".scratch.layer2_rn.weight"))
+    w.host.assign(host, host + numel);
   const int dt = k == WK_LIN16_BACKBONE ? h->cfg.backbone_dtype : h->cfg.head_dtype;
   std::vector<uint16_t> r;
   if (k == WK_LIN16_BACKBONE || k == WK_LIN16_HEAD) {
@@ -620,6 +646,7 @@ extern "C" wm_status wm_share_weights(wm_handle* dst, const wm_handle* src) {
   dst->missing = src->missing;
   dst->finalized = true;
   dst->plan_n = -1;
+  dst->tconv_valid = false;
   return WM_OK;
 }
 
@@ -727,6 +754,27 @@ wm_status plan(wm_handle* h, const Dims& d) {
       HIPCHK(h, hipMemcpy(h->buf["gs_posx"], tx.data(), tx.size() * 4, hipMemcpyHostToDevice));
       HIPCHK(h, hipMemcpy(h->buf["gs_posy"], ty.data(), ty.size() * 4, hipMemcpyHostToDevice));
     }
+  }
+  // the composed ConvTranspose -> layer_rn GEMMs of the DPT heads (weight-derived only: rebuilt after a weight change, not per shape)
+  if (!h->tconv_valid) {
+    for (auto& kv : h->tconv) free_tconv(kv.second);
+    h->tconv.clear();
+    std::vector<std::string> heads;
+    if (c.enable_pts) heads.push_back("pts_head.");
+    if (c.enable_depth) heads.push_back("depth_head.");
+    if (c.enable_norm) heads.push_back("norm_head.");
+    if (c.dpt_features == 256)
+      for (const std::string& p : heads)
+        for (int i = 0; i < 2; ++i) {
+          const Weight* wct = W(h, p + "resize_layers." + std::to_string(i) + ".weight");
+          const Weight* bct = W(h, p + "resize_layers." + std::to_string(i) + ".bias");
+          const Weight* wrn = W(h, p + "scratch.layer" + std::to_string(i + 1) + "_rn.weight");
+          const int k = i == 0 ? 4 : 2, oc = c.dpt_out_channels[i];
+          if (!wct || !bct || !wrn || wct->host.empty() || bct->host.empty() || wrn->host.empty() || oc % 64) continue;
+          if (wct->host.size() != (size_t)oc * oc * k * k || bct->host.size() != (size_t)oc || wrn->host.size() != (size_t)256 * oc * 9) continue;
+          HIPCHK(h, build_tconv(c.head_dtype, k, oc, oc, 256, wct->host.data(), bct->host.data(), wrn->host.data(), h->tconv[p + std::to_string(i)], nullptr));
+        }
+    h->tconv_valid = true;
   }
   // camera init token broadcast [nt][12]
   if (c.enable_cam) {
@@ -1094,6 +1142,91 @@ wm_status camera_head(Ctx& c, float* out_params) {
   return WM_OK;
 }
 
+// ---- token-conv: Conv2d(3x3, pad 1, no bias) o ConvTranspose2d(kernel = stride = k) composed at the token resolution (WmGemmArgs::tc_k)
+// For output phase (a, b) of token (i, j) the 3x3 taps land in at most two token rows and two token columns:
+//   rn[(k i + a, k j + b)] = sum over neighbours (di, dj) of M[a, b, di, dj] p[i + di][j + dj]  +  (sum over taps inside the image of W_rn[tap]) b_ct
+//   M[a, b, di, dj] = sum over taps (dy, dx) with floor((a + dy) / k) = di, floor((b + dx) / k) = dj of W_rn[tap] W_ct[(a + dy) mod k][(b + dx) mod k]
+// 36 (phase, neighbour) matrices for k = 4, 16 for k = 2, instead of k^2 x 9 tap products per token: 4.4x / 2.7x fewer flops than ConvTranspose
+// GEMM + 3x3 conv, no ConvTranspose output tensor, one rounding of the combined weight instead of two operand roundings.
+// wct: torch ConvTranspose2d weight [Cin][Cm][k][k], bct [Cm], wrn: torch Conv2d weight [F][Cm][3][3] (host fp32).  F must be 256.
+static hipError_t build_tconv(int dt, int k, int Cin, int Cm, int F_, const float* wct, const float* bct, const float* wrn, TconvPack& out, hipStream_t s) {
+  if (F_ != 256 || (k != 2 && k != 4) || Cin % 64 || Cm % 4) return hipErrorInvalidValue;
+  free_tconv(out);
+  out.k = k; out.cin = Cin;
+  const int k2 = k * k;
+  std::vector<float> a_tap((size_t)9 * F_ * Cm), b_ph((size_t)k2 * Cin * Cm);
+  for (int f = 0; f < F_; ++f)
+    for (int c = 0; c < Cm; ++c)
+      for (int t = 0; t < 9; ++t) a_tap[((size_t)t * F_ + f) * Cm + c] = wrn[((size_t)f * Cm + c) * 9 + t];
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int c = 0; c < Cm; ++c)
+      for (int ph = 0; ph < k2; ++ph) b_ph[((size_t)ph * Cin + ci) * Cm + c] = wct[((size_t)ci * Cm + c) * k2 + ph];
+  float *d_a = nullptr, *d_b = nullptr, *d_bct = nullptr, *d_m = nullptr;
+  hipError_t e;
+#define TC(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
+  TC(hipMalloc((void**)&d_a, a_tap.size() * 4));
+  TC(hipMalloc((void**)&d_b, b_ph.size() * 4));
+  TC(hipMalloc((void**)&d_bct, (size_t)Cm * 4));
+  TC(hipMalloc((void**)&d_m, (size_t)F_ * Cin * 4));
+  TC(hipMalloc(&out.w16, (size_t)k2 * 256 * 4 * Cin * 2));
+  TC(hipMalloc((void**)&out.bias_rep, (size_t)k2 * 256 * 4));
+  TC(hipMalloc((void**)&out.bmiss, (size_t)9 * 256 * 4));
+  TC(hipMemcpyAsync(d_a, a_tap.data(), a_tap.size() * 4, hipMemcpyHostToDevice, s));
+  TC(hipMemcpyAsync(d_b, b_ph.data(), b_ph.size() * 4, hipMemcpyHostToDevice, s));
+  TC(hipMemcpyAsync(d_bct, bct, (size_t)Cm * 4, hipMemcpyHostToDevice, s));
+  TC(hipMemsetAsync(out.w16, 0, (size_t)k2 * 256 * 4 * Cin * 2, s));
+  for (int a = 0; a < k; ++a)
+    for (int b = 0; b < k; ++b) {
+      const int ph = a * k + b;
+      unsigned word = 0;
+      int idx = 0;
+      for (int di = -1; di <= 1; ++di)
+        for (int dj = -1; dj <= 1; ++dj) {
+          bool first = true;
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+              const int ya = a + dy, xb = b + dx;
+              const int fi = ya < 0 ? -1 : ya / k, fj = xb < 0 ? -1 : xb / k;   // floor
+              if (fi != di || fj != dj) continue;
+              const int pa = ((ya % k) + k) % k, pb = ((xb % k) + k) % k;
+              TC(wm_launch_linear_f32(d_a + (size_t)((dy + 1) * 3 + dx + 1) * F_ * Cm, d_b + (size_t)(pa * k + pb) * Cin * Cm, nullptr, d_m, F_, Cin, Cm, Cm,
+                                      Cin, 0, 0, nullptr, first ? 0 : 1, s));
+              first = false;
+            }
+          if (first) continue;   // no tap of this phase lands in that neighbour
+          TC(wm_launch_f32_to_16_2d(d_m, Cin, (uint16_t*)out.w16 + (size_t)ph * 256 * 4 * Cin + (size_t)idx * Cin, 4 * Cin, F_, Cin, dt, s));
+          word |= (unsigned)((di + 1) | ((dj + 1) << 2)) << (4 * idx);
+          ++idx;
+        }
+      out.list[ph] = word | ((unsigned)idx << 16);
+    }
+  for (int t = 0; t < 9; ++t)   // bmiss[t] = W_rn[t] b_ct ; bias = their sum
+    TC(wm_launch_linear_f32(d_bct, d_a + (size_t)t * F_ * Cm, nullptr, out.bmiss + (size_t)t * 256, 1, F_, Cm, Cm, F_, 0, 0, nullptr, 0, s));
+  for (int t = 0; t < 9; ++t)
+    TC(wm_launch_linear_f32(d_bct, d_a + (size_t)t * F_ * Cm, nullptr, out.bias_rep, 1, F_, Cm, Cm, F_, 0, 0, nullptr, t ? 1 : 0, s));
+  for (int ph = 1; ph < k2; ++ph) TC(hipMemcpyAsync(out.bias_rep + (size_t)ph * 256, out.bias_rep, 256 * 4, hipMemcpyDeviceToDevice, s));
+  TC(hipStreamSynchronize(s));
+#undef TC
+done:
+  if (d_a) (void)hipFree(d_a);
+  if (d_b) (void)hipFree(d_b);
+  if (d_bct) (void)hipFree(d_bct);
+  if (d_m) (void)hipFree(d_m);
+  if (e != hipSuccess) free_tconv(out);
+  return e;
+}
+// rn = tconv(tokens): tokens16 [n][gh][gw][Cin] (16-bit) -> out fp32 [n][k gh][k gw][256]
+static hipError_t launch_tconv(const TconvPack& t, int dt, const void* tokens16, float* out, int n, int gh, int gw, const void* zero16, hipStream_t s) {
+  WmGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = tokens16; g.W = t.w16; g.C = out; g.bias = t.bias_rep; g.M = n * gh * gw; g.N = t.k * t.k * 256; g.K = 4 * t.cin; g.lda = t.cin; g.ldw = 4 * t.cin; g.ldc = 256;
+  g.dtype = dt; g.epi = WM_EPI_CONV; g.cv_h = gh; g.cv_w = gw; g.cv_cin = t.cin; g.cv_zero = zero16; g.tc_k = t.k;
+  memcpy(g.tc_list, t.list, sizeof(g.tc_list));
+  hipError_t e = wm_launch_gemm(g, s);
+  if (e != hipSuccess) return e;
+  return wm_launch_tconv_border(out, t.bmiss, n, t.k * gh, t.k * gw, 256, s);
+}
+
 // up_hs > 0: x is [N][up_hs][up_ws][Cin] and the conv runs on its align_corners bilinear resize to (Hi, Wi)
 // (+ position tables), fused into the 3x3 halo kernel's input staging.
 wm_status conv(Ctx& c, const float* x, const std::string& wname, bool bias, const float* resid, bool resid_relu, const float* resid2,
@@ -1174,6 +1307,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
   for (int v0 = 0; v0 < d.n; v0 += d.chunk) {
     const int n = std::min(d.chunk, d.n - v0);
     float* feats[4] = {HB("dpt_f0"), HB("dpt_f1"), HB("dpt_f2"), HB("dpt_f3")};
+    bool tconv_done[4] = {false, false, false, false};
     for (int i = 0; i < 4; ++i) {
       const float* tap = B<float>(h, ("tap" + std::to_string(i)).c_str()) + (size_t)v0 * d.P * D2;
       void* T16 = HB("dpt_T16");
@@ -1188,6 +1322,13 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
         void* P16 = HB("dpt_P16");
         st = gemm(c, c.hdt, WM_EPI_ROWMAP_ADD, T16, D2, W16(h, pj + ".weight"), D2, P16, oc[i], F(h, pj + ".bias"), nullptr, n * hw, oc[i], D2, &ex);
         if (st) return st;
+        auto tc = h->tconv.find(p + std::to_string(i));
+        tconv_done[i] = wm_tuning[WM_TUNE_TCONV] != 0 && !is_gs && F_ == 256 && tc != h->tconv.end() && tc->second.w16 != nullptr;
+        if (tconv_done[i]) {   // ConvTranspose and layer{i+1}_rn as one GEMM at the token resolution, straight into rn[i]
+          ProfScope ps(h, i == 0 ? 8 : 3, c.s);
+          LCHK(c, launch_tconv(tc->second, c.hdt, P16, HB(i == 0 ? "dpt_rn1" : "dpt_rn2"), n, gh, gw, B<uint16_t>(h, "ZERO256"), c.s));
+          continue;
+        }
         const int k = i == 0 ? 4 : 2;
         const std::string rs = p + "resize_layers." + std::to_string(i);
         WmGemmArgs ct;
@@ -1208,6 +1349,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     const int Hs[4] = {4 * gh, 2 * gh, gh, d.gh2}, Ws[4] = {4 * gw, 2 * gw, gw, d.gw2};
     float* rn[4] = {HB("dpt_rn1"), HB("dpt_rn2"), HB("dpt_rn3"), HB("dpt_rn4")};
     for (int i = 0; i < 4; ++i) {
+      if (tconv_done[i]) continue;
       st = conv(c, feats[i], sc + "layer" + std::to_string(i + 1) + "_rn", false, nullptr, false, nullptr, rn[i], n, Hs[i], Ws[i], 3, 1, 1, false);
       if (st) return st;
     }
@@ -1835,6 +1977,19 @@ extern "C" wm_status wm_op_upconv3x3_tap(int dtype, const void* x16, const void*
   g.A = x16; g.W = wt16; g.C = y16; g.M = N * Hi * Wi; g.N = 9 * Co; g.K = C; g.lda = C; g.ldw = C; g.ldc = 9 * Co; g.dtype = dtype; g.epi = WM_EPI_T16;
   if (wm_launch_gemm(g, s) != hipSuccess) return WM_ERR_HIP;
   return wm_launch_upconv_gather(y16, bias, out, N, Hi, Wi, Ho, Wo, Co, s) == hipSuccess ? WM_OK : WM_ERR_HIP;
+}
+// Conv2d(Cm, 256, 3, padding=1, bias=False)(ConvTranspose2d(Cin, Cm, k, stride=k)(tokens)) composed at the token resolution (build_tconv):
+// tokens16 [N][gh][gw][Cin] 16-bit device; wct [Cin][Cm][k][k], bct [Cm], wrn [256][Cm][3][3]: HOST fp32 in torch's layouts; out fp32 [N][k gh][k gw][256]
+extern "C" wm_status wm_op_tconv(int dtype, const void* tokens16, const float* wct, const float* bct, const float* wrn, float* out, int N, int gh, int gw,
+                                 int k, int Cin, int Cm, const void* zero16, void* stream) {
+  if (!tokens16 || !wct || !bct || !wrn || !out || !zero16) return WM_ERR_INVALID;
+  TconvPack t;
+  hipStream_t s = (hipStream_t)stream;
+  if (build_tconv(dtype, k, Cin, Cm, 256, wct, bct, wrn, t, s) != hipSuccess) return WM_ERR_HIP;
+  const hipError_t e = launch_tconv(t, dtype, tokens16, out, N, gh, gw, zero16, s);
+  (void)hipStreamSynchronize(s);
+  free_tconv(t);
+  return e == hipSuccess ? WM_OK : WM_ERR_HIP;
 }
 extern "C" wm_status wm_op_upconv_gather(const void* y16, const float* bias, float* out, int N, int Hi, int Wi, int Ho, int Wo, int Co, void* stream) {
   return wm_launch_upconv_gather(y16, bias, out, N, Hi, Wi, Ho, Wo, Co, (hipStream_t)stream) == hipSuccess ? WM_OK : WM_ERR_HIP;

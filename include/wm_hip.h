@@ -223,6 +223,15 @@ wm_status wm_op_up_conv_n32(int dtype, const float* x, const void* w16, const fl
 wm_status wm_op_conv_ex(int dtype, const void* x, int in16, const void* w16, const float* bias, const float* resid, const float* resid2,
                         void* y, int out16, int N, int Hi, int Wi, int Cin, int Cout, int relu_in, int resid_relu, int relu_out, void* stream);
 
+/* Operator-level entry (parity tests / A-B): Conv2d(Cm, 256, 3, padding=1, bias=False)(ConvTranspose2d(Cin, Cm, k, stride=k)(tokens)) — the DPT
+ * head's resize_layers[0 / 1] followed by scratch.layer{1,2}_rn (dense_head.py:57-66,196-214,277-278,394-399) — composed into ONE block-sparse GEMM
+ * at the token resolution: per output phase the 3x3 taps land in at most 2 x 2 neighbouring tokens, so 36 (k = 4) / 16 (k = 2) combined
+ * matrices replace k^2 x 9 tap products per token.  tokens16: device, 16-bit NHWC [N][gh][gw][Cin]; wct [Cin][Cm][k][k], bct [Cm], wrn
+ * [256][Cm][3][3]: HOST fp32, torch layouts (combined in fp32 on the device, rounded once); out: device fp32 NHWC [N][k*gh][k*gw][256];
+ * zero16: >= 128 B of device zeros.  k in {2, 4}; Cin % 64 == 0.  Synchronises the stream (it builds and frees the combined weights). */
+wm_status wm_op_tconv(int dtype, const void* tokens16, const float* wct, const float* bct, const float* wrn, float* out, int N, int gh, int gw,
+                      int k, int Cin, int Cm, const void* zero16, void* stream);
+
 /* Operator-level entry (parity tests / A-B): Conv2d(C, Co, 3, padding=1)(F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=True)) —
  * the DPT head's output_conv1 behind its last resize (dense_head.py:217-225,265-295) — in the tap form: the nine 1x1 products W_tap x at the
  * LOW resolution (one GEMM, a quarter of the direct conv's flops) and a bilinear gather of them.  x16: f16 NHWC [N][Hi][Wi][C]; w16:

@@ -145,6 +145,34 @@ def test_c2_forward_with_rcu_conv2_as_pingpong_gemm(model_and_out):
         assert 0 < e < 1.5e-3, (k, e)
 
 
+def test_c2_composed_head_convs_match_the_direct_forms(model_and_out):
+    """Round 4's two algebraic rewrites of the DPT heads, both default: (1) resize_layers[0 / 1] (ConvTranspose, kernel = stride) composed with
+    scratch.layer{1,2}_rn (3x3) into one block-sparse GEMM at the token resolution (tuning tconv; dense_head.py:57-66,277-278), (2) output_conv1
+    behind the last resize as nine low-resolution 1x1 products + a bilinear gather (tuning up1_gather; dense_head.py:217-225).  Linear maps
+    regrouped, so the outputs equal the direct forms' up to where the 16-bit roundings fall (this fixture's weights are the sensitivity-
+    maximising preset); the backbone and the camera head are untouched (bit-identical); each form on its own also matches."""
+    from hunyuanworld_mirror_amd import _lib
+    m, img, out = model_and_out
+    L = _lib.lib()
+    res = {}
+    for name, kv in (("direct", ((b"tconv", 0), (b"up1_gather", 0))), ("tconv_only", ((b"up1_gather", 0),)), ("up1_only", ((b"tconv", 0),))):
+        for k, v in kv:
+            assert L.wm_set_tuning(k, v) == 0
+        try:
+            res[name] = m({"img": img})
+            torch.cuda.synchronize()
+        finally:
+            for k, _ in kv:
+                L.wm_set_tuning(k, -1)
+    for name, r in res.items():
+        assert torch.equal(r["camera_params"], out["camera_params"]), name
+        for k in ("pts3d", "depth", "normals", "pts3d_conf"):
+            assert torch.isfinite(r[k]).all(), (name, k)
+            e = rel_l2(out[k].cpu().numpy(), r[k].cpu().numpy())
+            print(f"default vs {name}", k, f"{e:.2e}")
+            assert 0 < e < 1.5e-3, (name, k, e)
+
+
 def test_c2_view_permutation_equivariance(model_and_out):
     """Views 1..N-1 are exchangeable (only view 0 carries the reference-frame tokens,
     visual_transformer.py:397-416): swapping two of them swaps their outputs.  Not bitwise: the key order of the

@@ -1009,6 +1009,35 @@ def test_up_conv_n32_unfused(dev, N, Hs, Ws, Hi, Wi, Cin):
         assert torch.equal(again, y2)
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("N,gh,gw,k,Cin", [(2, 16, 16, 4, 256), (3, 10, 7, 2, 512), (1, 37, 37, 4, 256), (8, 37, 37, 2, 512), (1, 1, 5, 4, 64), (2, 3, 1, 2, 128)])
+def test_token_conv_composition(dev, dt, N, gh, gw, k, Cin):
+    """wm_op_tconv: Conv2d(3x3, pad 1, no bias) o ConvTranspose2d(kernel = stride = k) as ONE block-sparse GEMM at the token resolution
+    (per output phase the combined matrices of the <= 2 x 2 neighbour tokens its taps land in; gemm.hip WM_EPI_CONV tc_k, wm_model.cpp
+    build_tconv) — against fp32 torch conv2d(conv_transpose2d(tokens)) on the same 16-bit tokens: interior, the image border (zero
+    padding of the 3x3 sees neither neighbour tokens nor the ConvTranspose bias there), single-row / single-column token grids, both k."""
+    g = torch.Generator().manual_seed(N * 7 + gh + k + Cin + dt)
+    tok = _t16(torch.randn(N, gh, gw, Cin, generator=g), dt).to(dev)
+    wct = torch.randn(Cin, Cin, k, k, generator=g) / math.sqrt(Cin)
+    bct = torch.randn(Cin, generator=g)
+    wrn = torch.randn(256, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    out = torch.full((N, k * gh, k * gw, 256), float("nan"), device=dev)
+    zero = torch.zeros(128, dtype=torch.int16, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    hp = lambda t: C.c_void_p(t.data_ptr())
+    assert _lib().wm_op_tconv(dt, _p(tok), hp(wct), hp(bct), hp(wrn), _p(out), N, gh, gw, k, Cin, Cin, _p(zero), s) == 0
+    torch.cuda.synchronize()
+    x = tok.float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.conv_transpose2d(x, wct.to(dev), bct.to(dev), stride=k), wrn.to(dev), None, padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(out).all()
+    e = _rel(out, ref)
+    print(f"token conv {N}x{gh}x{gw} k{k} {Cin}->256 dt{dt}: {e:.2e}")
+    assert e < (6e-4 if dt == F16 else 5e-3), e      # one rounding of each combined weight to the operand type (2^-11 / 2^-8), fp32 accumulation
+    b = (out - ref).abs()
+    border = torch.cat([b[:, 0].flatten(), b[:, -1].flatten(), b[:, :, 0].flatten(), b[:, :, -1].flatten()])
+    assert border.max() <= 4 * b.max().clamp_min(1e-6) and border.mean() < 3 * b.mean() + 1e-6   # the border is no worse than the interior
+
+
 @pytest.mark.parametrize("N,Hi,Wi,Ho,Wo,Cin,Co", [(2, 20, 16, 40, 32, 256, 128), (1, 9, 11, 33, 40, 64, 64), (3, 37, 37, 74, 74, 256, 128),
                                                   (1, 148, 148, 296, 296, 256, 128), (2, 12, 10, 12, 10, 128, 32), (1, 5, 7, 1, 1, 64, 32)])
 def test_upconv3x3_tap_form(dev, N, Hi, Wi, Ho, Wo, Cin, Co):
