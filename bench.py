@@ -357,7 +357,10 @@ def main():
                 "avg_launch_ms": kernels[dom]["avg_ms"], "flops_per_launch": fl[dom] / kernels[dom]["launches"],
                 "kernels": kernels, "classes": classes,
                 "kernels_note": "per-kernel times come from ONE serial, HIP-event-timed forward run after the timed region; the timed region "
-                                "itself runs the camera head and the DPT heads on their own queues, so ms_per_step < forward_ms_events", "forward_ms_events": round(whole_ms, 3),
+                                "itself runs the camera head and the DPT heads on their own queues, so ms_per_step < forward_ms_events.  TFLOP/s are the "
+                                "REFERENCE's algorithmic flops over time: the DPT heads run two algebraically reduced forms (ConvTranspose composed with "
+                                "layer_rn at the token resolution; output_conv1 as nine low-resolution 1x1 products + a gather), so dpt_conv executes "
+                                "fewer MFMA flops than the class's figure counts", "forward_ms_events": round(whole_ms, 3),
                 "per_gpu_algorithmic_tflop": round(fl["total"] / 1e12, 2),
                 "whole_forward_tflops": round(fl["total"] / (ms_step * 1e-3) / 1e12, 1),
                 "whole_forward_frac": round(fl["total"] / (ms_step * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}

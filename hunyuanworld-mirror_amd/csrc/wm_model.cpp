@@ -1370,7 +1370,8 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
     // output_conv1 on the resized tensor as nine 1x1 products at the LOW resolution + a bilinear gather (upconv.hip): a quarter of the MFMA work
     const Weight* w_oc1 = W(h, sc + "output_conv1.weight");
     const bool gather_on = wm_tuning[WM_TUNE_UP1_GATHER] != 0 && c.hdt == WM_DT_F16 && w_oc1 && w_oc1->tap_major && F_ % 64 == 0 &&
-                           (int)w_oc1->shape[1] == F_ && ((int)w_oc1->shape[0] == 128 || (int)w_oc1->shape[0] == 64 || (int)w_oc1->shape[0] == 32);
+                           (int)w_oc1->shape[1] == F_ && ((int)w_oc1->shape[0] == 128 || (int)w_oc1->shape[0] == 64 || (int)w_oc1->shape[0] == 32) &&
+                           (unsigned long long)n * Hs[0] * Ws[0] * 9ull * (unsigned long long)w_oc1->shape[0] * 2ull < (1ull << 32);   // the gather's 32-bit offsets
     bool up1_gather = false;
     for (int L = 2; L >= 0; --L) {  // refinenet3 (level 2), refinenet2 (level 1), refinenet1 (level 0)
       const std::string rp = sc + "refinenet" + std::to_string(L + 1) + ".";

@@ -3,11 +3,11 @@
 # cpu_baseline + parity + north-star leg; C3; the C5 flag set), rocprofv3 kernel trace + stats of the C2 workload, the PMC passes (HBM
 # traffic; matrix-pipe busy; wave-cycle split), each its own run as the guides prescribe, the GEMM timeline / yardsticks / one-part-removed
 # builds / schedule A/B, the forward A/B against round 3's GEMM, and the sink-shaped attention rows.
-# usage: bash tools/collect_r04_evidence.sh [stage ...]   (stages: bench prof pmc c3 c5 gemm ab spike; default all)
+# usage: bash tools/collect_r04_evidence.sh [stage ...]   (stages: bench prof pmc c3 c5 gemm ab heads spike; default all)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
-stages=${@:-bench prof pmc c3 c5 gemm ab spike}
+stages=${@:-bench prof pmc c3 c5 gemm ab heads spike}
 B="python3 $R/bench.py"
 S=$R/hunyuanworld-mirror_amd/libwm_hip_stamps.so
 for st in $stages; do
@@ -36,6 +36,12 @@ gemm)
 ab)
   cd $R
   timeout -k 10 300 python3 tools/ab_forward.py 8 default: r03gemm:gemm_sched=0 > $O/ab_forward_8v.jsonl 2>/dev/null; echo "ab rc $?"
+  cd /tmp;;
+heads)
+  cd $R
+  timeout -k 10 300 python3 tools/ab_forward.py 8 default: direct:tconv=0,up1_gather=0 default2: tconv_only:up1_gather=0 default3: up1_only:tconv=0 direct2:tconv=0,up1_gather=0 > $O/ab_head_rewrites.jsonl 2>/dev/null; echo "heads ab rc $?"
+  timeout -k 10 200 python3 tools/bench_upconv_parts.py > $O/upconv_parts.jsonl 2>/dev/null; echo "parts rc $?"
+  timeout -k 10 200 python3 tools/bench_conv_gemm.py > $O/dpt_conv_forms.jsonl 2>/dev/null; echo "forms rc $?"
   cd /tmp;;
 spike)
   cd $R
