@@ -51,7 +51,7 @@ EXPORTS = [
     "wm_local_group_create", "wm_local_group_destroy", "wm_comm_init_local", "wm_allgather", "wm_profile_enable", "wm_profile_read",
     "wm_op_gemm", "wm_op_gemm_resid_ln", "wm_op_gemm_qkv", "wm_op_attention", "wm_op_layernorm", "wm_op_qkv_post", "wm_op_conv", "wm_op_bilinear",
     "wm_op_linear_f32", "wm_host_to_16", "wm_set_tuning", "wm_op_attention_split", "wm_op_attention_ex", "wm_op_attention_flag_count", "wm_op_gs_splat", "wm_op_conv3x3_up", "wm_depth_to_world", "wm_confidence_mask", "wm_confidence_mask_workspace_bytes", "wm_preprocess_image", "wm_preprocess_image_size",
-    "wm_preprocess_image_workspace_bytes", "wm_rasterize_splats", "wm_rasterize_workspace_bytes", "wm_prune_gs", "wm_prune_gs_workspace_bytes", "wm_op_up_conv_n32", "wm_op_conv3x3_gemm16", "wm_op_conv_ex", "wm_op_upconv3x3_tap", "wm_op_tconv",
+    "wm_preprocess_image_workspace_bytes", "wm_rasterize_splats", "wm_rasterize_workspace_bytes", "wm_prune_gs", "wm_prune_gs_workspace_bytes", "wm_op_up_conv_n32", "wm_op_conv3x3_gemm16", "wm_op_conv_ex", "wm_op_upconv3x3_tap", "wm_op_tconv", "wm_op_upconv_gather",
 ]
 
 _lib = None
@@ -127,6 +127,8 @@ def lib() -> C.CDLL:
     L.wm_op_upconv3x3_tap.restype = i32
     L.wm_op_tconv.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.wm_op_tconv.restype = i32
+    L.wm_op_upconv_gather.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.wm_op_upconv_gather.restype = i32
     L.wm_prune_gs_workspace_bytes.argtypes = [C.c_size_t]
     L.wm_prune_gs_workspace_bytes.restype = C.c_size_t
     L.wm_prune_gs.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp, C.POINTER(i32), vp, C.c_size_t, vp]

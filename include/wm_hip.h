@@ -240,6 +240,9 @@ wm_status wm_op_tconv(int dtype, const void* tokens16, const float* wct, const f
 wm_status wm_op_upconv3x3_tap(int dtype, const void* x16, const void* w16, const float* bias, float* out, int N, int Hi, int Wi, int Ho,
                               int Wo, int C, int Co, void* wt16, void* y16, void* stream);
 
+/* The gather half of wm_op_upconv3x3_tap on its own (timing tools): y16 f16 [N][Hi][Wi][9][Co] -> out fp32 [N][Ho][Wo][Co] (+ bias). */
+wm_status wm_op_upconv_gather(const void* y16, const float* bias, float* out, int N, int Hi, int Wi, int Ho, int Wo, int Co, void* stream);
+
 /* Operator-level entry (parity tests / A-B): Conv2d(Cin, Cout, 3, padding=1) on a 16-BIT NHWC tensor x16 [N][H][W][Cin] of the operand
  * type, run as the ping-pong GEMM itself (rows = pixels, K = (tap, channel); no im2col): y = conv(x16) + bias + relu?(resid) + resid2,
  * optional ReLU; y is fp32 NHWC, or 16-bit NHWC when out16.  The form the ResidualConvUnit's second conv takes (dense_head.py:435-455)

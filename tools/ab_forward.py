@@ -14,7 +14,11 @@ for a in args:
     name, _, kv = a.partition(":")
     arms.append((name, [(k.encode(), int(v)) for k, v in (x.split("=") for x in kv.split(",") if x)]))
 keys = sorted({k for _, kvs in arms for k, _ in kvs})
-m = WorldMirror(arch=WMConfig(), dtype="bf16").to(dev).init_synthetic_weights()
+import os
+GS, DT = os.environ.get("AB_GS") == "1", os.environ.get("AB_DTYPE", "bf16")   # (AB_GS=1 AB_DTYPE=f16: BASELINE C5's flag set)
+m = WorldMirror(arch=WMConfig(enable_gs=True) if GS else WMConfig(), dtype=DT).to(dev).init_synthetic_weights()
+if GS:
+    m.enable_prune = False
 g = torch.Generator().manual_seed(1234)
 v = {"img": torch.rand(1, S, 3, 518, 518, generator=g).to(dev)}
 m.reserve(S, S, 518, 518)

@@ -6,7 +6,6 @@ L = importlib.import_module("hunyuanworld_mirror_amd._lib").lib()
 dev = torch.device("cuda:0")
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-L.wm_op_upconv_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
 def timeit(fn, n=5, reps=9):
     for _ in range(3): assert fn() == 0
     ts = []
