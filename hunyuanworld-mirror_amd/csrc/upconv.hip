@@ -117,11 +117,17 @@ __global__ __launch_bounds__(256) void upconv_gather_lds_kernel(const uint16_t* 
   __shared__ uint4 lds[UG_RMAX * UG_CMAX * UG_REC + 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntx = (Wo + UG_TX - 1) / UG_TX, nty = (Ho + UG_TY - 1) / UG_TY;
-  const int g = blockIdx.x % NG;
-  int tile = blockIdx.x / NG;
+  // The NG channel-group blocks of one tile read the same 128-byte lines (64 B of each tap piece per group): keep them on ONE XCD's L2 — workgroups
+  // go round-robin over the 8 XCDs, so the group index is taken from bits above the low three of the block index (PMC, first form: the groups of a
+  // tile sat on NG different XCDs and the launch fetched 650 MB for 404 MB of products)
+  const int nb = gridDim.x;
+  int g, tile;
+  if (NG > 1 && (nb / NG) % 8 == 0) { const int b = blockIdx.x; g = (b >> 3) % NG; tile = (b / (8 * NG)) * 8 + (b & 7); }
+  else { g = blockIdx.x % NG; tile = blockIdx.x / NG; }
   const int X0 = (tile % ntx) * UG_TX;
   tile /= ntx;
   const int Y0 = (tile % nty) * UG_TY, n = tile / nty;
+  if (n >= N) return;   // padding blocks
   const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
   const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
   auto lo_of = [](float sc, int p, int lim) { int v = (int)(sc * (float)p); return v < lim - 1 ? v : lim - 1; };
@@ -282,7 +288,8 @@ hipError_t wm_launch_upconv_gather(const void* y16, const float* bias, float* ou
   const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
   // rows a tile samples: floor(sy yhi) + 1 - floor(sy ylo) + 1 with yhi - ylo <= TY + 1, i.e. at most ceil(sy (TY + 1)) + 2 (same for columns)
   if (lds_ok && (int)ceilf(sy * (UG_TY + 1)) + 2 <= UG_RMAX && (int)ceilf(sx * (UG_TX + 1)) + 2 <= UG_CMAX) {
-    const dim3 grid((unsigned)((size_t)N * ((Ho + UG_TY - 1) / UG_TY) * ((Wo + UG_TX - 1) / UG_TX) * (Co / 32)));
+    const size_t tiles = (size_t)N * ((Ho + UG_TY - 1) / UG_TY) * ((Wo + UG_TX - 1) / UG_TX);
+    const dim3 grid((unsigned)(((tiles + 7) / 8 * 8) * (Co / 32)));   // tiles padded to eights (XCD-aware group mapping; surplus blocks exit)
     if (Co == 128) hipLaunchKernelGGL(upconv_gather_lds_kernel<16>, grid, dim3(256), 0, s, (const uint16_t*)y16, bias, out, N, Hi, Wi, Ho, Wo);
     else if (Co == 64) hipLaunchKernelGGL(upconv_gather_lds_kernel<8>, grid, dim3(256), 0, s, (const uint16_t*)y16, bias, out, N, Hi, Wi, Ho, Wo);
     else hipLaunchKernelGGL(upconv_gather_lds_kernel<4>, grid, dim3(256), 0, s, (const uint16_t*)y16, bias, out, N, Hi, Wi, Ho, Wo);
