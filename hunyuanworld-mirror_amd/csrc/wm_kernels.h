@@ -274,6 +274,6 @@ hipError_t wm_launch_prune_gs(const float* means, const float* quats, const floa
                               const float* weights, int N, float voxel, float* o_means, float* o_quats, float* o_scales, float* o_opac,
                               float* o_sh, int* K_out, void* workspace, size_t ws_bytes, hipStream_t s);
 
-enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_CONV_GEMM, WM_TUNE_RESID_PREFETCH, WM_TUNE_UP1_GATHER, WM_TUNE_TCONV, WM_TUNE_COUNT };
+enum { WM_TUNE_GEMM_CFG = 0, WM_TUNE_GEMM_PP, WM_TUNE_GEMM_MFMA16, WM_TUNE_ATTN_QB, WM_TUNE_OP_LDPAD, WM_TUNE_ATTN_SPLITS, WM_TUNE_CONV_FUSE_UP, WM_TUNE_CONV_NARROW, WM_TUNE_CONV_BN, WM_TUNE_CONV_RS, WM_TUNE_LIN_MFMA, WM_TUNE_CONV_TPX, WM_TUNE_ATTN_TAIL, WM_TUNE_GEMM_GROUP, WM_TUNE_COMM_OVERLAP, WM_TUNE_HEADS_CONC, WM_TUNE_RCU_MID16, WM_TUNE_GEMM_SCHED, WM_TUNE_FORCE_GATHER, WM_TUNE_ATTN_OP_POLICY, WM_TUNE_COMM_P2P, WM_TUNE_LN_RPW, WM_TUNE_LN_FUSE, WM_TUNE_HEADS_MAIN, WM_TUNE_CONV_GEMM, WM_TUNE_RESID_PREFETCH, WM_TUNE_UP1_GATHER, WM_TUNE_TCONV, WM_TUNE_UP1_COMP, WM_TUNE_COUNT };
 extern int wm_tuning[WM_TUNE_COUNT];
 

@@ -67,6 +67,19 @@ static void free_tconv(TconvPack& t) {
 }
 
 static hipError_t build_tconv(int dt, int k, int Cin, int Cm, int F_, const float* wct, const float* bct, const float* wrn, TconvPack& out, hipStream_t s);
+// refinenet1.out_conv (1x1) composed into the nine tap matrices of output_conv1 (upconv.hip): the tap GEMM then reads the last fusion block's
+// 16-bit tensor directly — W[tap][co][ci] = sum_c W_oc1[co][c][tap] W_out[c][ci], bias[tap][co] = sum_c W_oc1[co][c][tap] b_out[c] (build_up1comp)
+struct Up1Comp {
+  void* w16 = nullptr;     // [9 Co][F] 16-bit
+  float* bias = nullptr;   // [9 Co]
+  int co = 0;
+};
+static void free_up1comp(Up1Comp& u) {
+  if (u.w16) (void)hipFree(u.w16);
+  if (u.bias) (void)hipFree(u.bias);
+  u = Up1Comp();
+}
+static hipError_t build_up1comp(int dt, int F_, int Co, const float* woc1, const float* wout, const float* bout, Up1Comp& out, hipStream_t s);
 
 struct EvPair { hipEvent_t a, b; };
 
@@ -100,6 +113,7 @@ struct wm_handle {
   int plan_n = -1, plan_nt = -1, plan_H = -1, plan_W = -1;
   std::map<std::string, TconvPack> tconv;   // per head and level ("pts_head.0"): rebuilt by wm_reserve after a weight change
   bool tconv_valid = false;
+  std::map<std::string, Up1Comp> up1comp;   // per head ("pts_head."), rebuilt with the token-conv packs
   std::vector<std::string> missing;  // names wm_finalize_weights filled with their init values
   // shape-dependent device tables (allocated inside the arena by plan())
   std::map<std::string, void*> buf;
@@ -464,7 +478,7 @@ extern "C" void wm_host_resample_pos(const float* in, int gs, int D, int gh, int
 }
 
 extern "C" int wm_set_tuning(const char* key, int value) {
-  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main", "conv_gemm", "resid_prefetch", "up1_gather", "tconv"};
+  static const char* keys[WM_TUNE_COUNT] = {"gemm_cfg", "gemm_pp", "gemm_mfma16", "attn_qb", "op_ldpad", "attn_splits", "conv_fuse_up", "conv_narrow", "conv_bn", "conv_rs", "lin_mfma", "conv_tpx", "attn_tail", "gemm_group", "comm_overlap", "heads_concurrent", "rcu_mid16", "gemm_sched", "force_gather", "attn_op_policy", "comm_p2p", "ln_rpw", "ln_fuse", "heads_main", "conv_gemm", "resid_prefetch", "up1_gather", "tconv", "up1_comp"};
   for (int i = 0; i < WM_TUNE_COUNT; ++i)
     if (key && strcmp(key, keys[i]) == 0) { wm_tuning[i] = value; return 0; }
   return -1;
@@ -492,6 +506,7 @@ extern "C" void wm_destroy(wm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   for (auto& kv : h->tconv) free_tconv(kv.second);
+  for (auto& kv : h->up1comp) free_up1comp(kv.second);
   for (auto& kv : h->w) {
     if (!kv.second.owned) continue;
     if (kv.second.f32) (void)hipFree(kv.second.f32);
@@ -546,12 +561,15 @@ extern "C" wm_status wm_set_weight(wm_handle* h, const char* name, const float* 
     HIPCHK(h, hipMalloc((void**)&w.f32, std::max<size_t>(numel, 4) * 4));
     HIPCHK(h, hipMemcpy(w.f32, host, numel * 4, hipMemcpyHostToDevice));
     if (ends_with(n, "pos_embed") || ends_with(n, "init_token")) w.host.assign(host, host + numel);
-    if (n.find(".resize_layers.0.bias") != std::string::npos || n.find(".resize_layers.1.bias") != std::string::npos) w.host.assign(host, host + numel);
+    if (n.find(".resize_layers.0.bias") != std::string::npos || n.find(".resize_layers.1.bias") != std::string::npos ||
+        ends_with(n, ".scratch.refinenet1.out_conv.bias"))
+      w.host.assign(host, host + numel);
     return WM_OK;
   }
   // the ConvTranspose / layer_rn pairs that wm_reserve composes into one token-resolution GEMM (build_tconv) are kept in fp32 on the host
   if (n.find(".resize_layers.0.weight") != std::string::npos || n.find(".resize_layers.1.weight") != std::string::npos ||
-      ends_with(n, ".scratch.layer1_rn.weight") || ends_with(n, ".scratch.layer2_rn.weight"))
+      ends_with(n, ".scratch.layer1_rn.weight") || ends_with(n, ".scratch.layer2_rn.weight") ||
+      ends_with(n, ".scratch.refinenet1.out_conv.weight") || ends_with(n, ".scratch.output_conv1.weight"))   // (+ build_up1comp)
     w.host.assign(host, host + numel);
   const int dt = k == WK_LIN16_BACKBONE ? h->cfg.backbone_dtype : h->cfg.head_dtype;
   std::vector<uint16_t> r;
@@ -758,6 +776,7 @@ wm_status plan(wm_handle* h, const Dims& d) {
   // the composed ConvTranspose -> layer_rn GEMMs of the DPT heads (weight-derived only: rebuilt after a weight change, not per shape)
   if (!h->tconv_valid) {
     for (auto& kv : h->tconv) free_tconv(kv.second);
+  for (auto& kv : h->up1comp) free_up1comp(kv.second);
     h->tconv.clear();
     std::vector<std::string> heads;
     if (c.enable_pts) heads.push_back("pts_head.");
@@ -774,6 +793,18 @@ wm_status plan(wm_handle* h, const Dims& d) {
           if (wct->host.size() != (size_t)oc * oc * k * k || bct->host.size() != (size_t)oc || wrn->host.size() != (size_t)256 * oc * 9) continue;
           HIPCHK(h, build_tconv(c.head_dtype, k, oc, oc, 256, wct->host.data(), bct->host.data(), wrn->host.data(), h->tconv[p + std::to_string(i)], nullptr));
         }
+    h->up1comp.clear();
+    if (c.head_dtype == WM_DT_F16)
+      for (const std::string& p : heads) {
+        const Weight* w1 = W(h, p + "scratch.output_conv1.weight");
+        const Weight* wo = W(h, p + "scratch.refinenet1.out_conv.weight");
+        const Weight* bo = W(h, p + "scratch.refinenet1.out_conv.bias");
+        const int F_ = c.dpt_features;
+        if (!w1 || !wo || !bo || w1->host.empty() || wo->host.empty() || bo->host.empty() || F_ % 64 || w1->shape.size() != 4) continue;
+        const int Co = (int)w1->shape[0];
+        if ((Co != 128 && Co != 64 && Co != 32) || w1->host.size() != (size_t)Co * F_ * 9 || wo->host.size() != (size_t)F_ * F_ || bo->host.size() != (size_t)F_) continue;
+        HIPCHK(h, build_up1comp(c.head_dtype, F_, Co, w1->host.data(), wo->host.data(), bo->host.data(), h->up1comp[p], nullptr));
+      }
     h->tconv_valid = true;
   }
   // camera init token broadcast [nt][12]
@@ -1215,6 +1246,42 @@ done:
   if (e != hipSuccess) free_tconv(out);
   return e;
 }
+// woc1: torch Conv2d weight [Co][F][3][3]; wout: [F][F] (1x1); bout [F] (host fp32)
+static hipError_t build_up1comp(int dt, int F_, int Co, const float* woc1, const float* wout, const float* bout, Up1Comp& out, hipStream_t s) {
+  free_up1comp(out);
+  out.co = Co;
+  std::vector<float> a_tap((size_t)9 * Co * F_), wt((size_t)F_ * F_);
+  for (int co = 0; co < Co; ++co)
+    for (int c = 0; c < F_; ++c)
+      for (int t = 0; t < 9; ++t) a_tap[((size_t)t * Co + co) * F_ + c] = woc1[((size_t)co * F_ + c) * 9 + t];
+  for (int c = 0; c < F_; ++c)
+    for (int ci = 0; ci < F_; ++ci) wt[(size_t)ci * F_ + c] = wout[(size_t)c * F_ + ci];   // W_out^T: rows ci, K = c
+  float *d_a = nullptr, *d_w = nullptr, *d_b = nullptr, *d_m = nullptr;
+  hipError_t e;
+#define TC(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
+  TC(hipMalloc((void**)&d_a, a_tap.size() * 4));
+  TC(hipMalloc((void**)&d_w, wt.size() * 4));
+  TC(hipMalloc((void**)&d_b, (size_t)F_ * 4));
+  TC(hipMalloc((void**)&d_m, (size_t)9 * Co * F_ * 4));
+  TC(hipMalloc(&out.w16, (size_t)9 * Co * F_ * 2));
+  TC(hipMalloc((void**)&out.bias, (size_t)9 * Co * 4));
+  TC(hipMemcpyAsync(d_a, a_tap.data(), a_tap.size() * 4, hipMemcpyHostToDevice, s));
+  TC(hipMemcpyAsync(d_w, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, s));
+  TC(hipMemcpyAsync(d_b, bout, (size_t)F_ * 4, hipMemcpyHostToDevice, s));
+  // all nine taps at once: rows (tap, co) of a_tap against W_out^T -> [9 Co][F]; the bias rows the same against b_out
+  TC(wm_launch_linear_f32(d_a, d_w, nullptr, d_m, 9 * Co, F_, F_, F_, F_, 0, 0, nullptr, 0, s));
+  TC(wm_launch_f32_to_16_2d(d_m, F_, out.w16, F_, 9 * Co, F_, dt, s));
+  TC(wm_launch_linear_f32(d_b, d_a, nullptr, out.bias, 1, 9 * Co, F_, F_, 9 * Co, 0, 0, nullptr, 0, s));
+  TC(hipStreamSynchronize(s));
+#undef TC
+done:
+  if (d_a) (void)hipFree(d_a);
+  if (d_w) (void)hipFree(d_w);
+  if (d_b) (void)hipFree(d_b);
+  if (d_m) (void)hipFree(d_m);
+  if (e != hipSuccess) free_up1comp(out);
+  return e;
+}
 // rn = tconv(tokens): tokens16 [n][gh][gw][Cin] (16-bit) -> out fp32 [n][k gh][k gw][256]
 static hipError_t launch_tconv(const TconvPack& t, int dt, const void* tokens16, float* out, int n, int gh, int gw, const void* zero16, hipStream_t s) {
   WmGemmArgs g;
@@ -1373,6 +1440,11 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
                            (int)w_oc1->shape[1] == F_ && ((int)w_oc1->shape[0] == 128 || (int)w_oc1->shape[0] == 64 || (int)w_oc1->shape[0] == 32) &&
                            (unsigned long long)n * Hs[0] * Ws[0] * 9ull * (unsigned long long)w_oc1->shape[0] * 2ull < (1ull << 32);   // the gather's 32-bit offsets
     bool up1_gather = false;
+    const Up1Comp* comp = nullptr;
+    {
+      auto it = h->up1comp.find(p);
+      if (gather_on && wm_tuning[WM_TUNE_UP1_COMP] != 0 && it != h->up1comp.end() && it->second.w16 && it->second.co == (int)w_oc1->shape[0]) comp = &it->second;
+    }
     for (int L = 2; L >= 0; --L) {  // refinenet3 (level 2), refinenet2 (level 1), refinenet1 (level 0)
       const std::string rp = sc + "refinenet" + std::to_string(L + 1) + ".";
       float* others[3];
@@ -1386,6 +1458,7 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       if (st) return st;
       const int Ho = L > 0 ? Hs[L - 1] : 2 * Hs[0], Wo = L > 0 ? Ws[L - 1] : 2 * Ws[0];
       up1_gather = L == 0 && gather_on && x16;
+      if (up1_gather && comp != nullptr) { cur = others[2]; break; }   // out_conv lives inside the tap matrices: the tap GEMM reads x2 itself
       st = out_conv(c, rp + "out_conv", others[2], x16, others[0], n, Hs[L], Ws[L], F_, up1_gather);
       if (st) return st;
       if (L == 0 && (fuse_up1 || up1_gather)) { cur = others[0]; break; }  // the last resize is fused into output_conv1 (its input staging, or the tap form)
@@ -1402,7 +1475,8 @@ wm_status dpt_head(Ctx& c, const std::string& p, int F_, int out_dim, int act, b
       const int Co = (int)w_oc1->shape[0];
       const size_t numel = (size_t)Co * 9 * F_;
       void* Y1 = others[1];
-      st = gemm(c, c.hdt, WM_EPI_T16, cur, F_, (const uint16_t*)w_oc1->w16 + numel, F_, Y1, 9 * Co, nullptr, nullptr, n * Hs[0] * Ws[0], 9 * Co, F_, nullptr, 10);
+      if (comp) st = gemm(c, c.hdt, WM_EPI_T16, cur, F_, comp->w16, F_, Y1, 9 * Co, comp->bias, nullptr, n * Hs[0] * Ws[0], 9 * Co, F_, nullptr, 10);
+      else st = gemm(c, c.hdt, WM_EPI_T16, cur, F_, (const uint16_t*)w_oc1->w16 + numel, F_, Y1, 9 * Co, nullptr, nullptr, n * Hs[0] * Ws[0], 9 * Co, F_, nullptr, 10);
       if (!st) {
         ProfScope ps(h, 10, c.s);
         LCHK(c, wm_launch_upconv_gather(Y1, F(h, sc + "output_conv1.bias"), others[0], n, Hs[0], Ws[0], H8, W8, Co, c.s));

@@ -148,14 +148,16 @@ def test_c2_forward_with_rcu_conv2_as_pingpong_gemm(model_and_out):
 def test_c2_composed_head_convs_match_the_direct_forms(model_and_out):
     """Round 4's two algebraic rewrites of the DPT heads, both default: (1) resize_layers[0 / 1] (ConvTranspose, kernel = stride) composed with
     scratch.layer{1,2}_rn (3x3) into one block-sparse GEMM at the token resolution (tuning tconv; dense_head.py:57-66,277-278), (2) output_conv1
-    behind the last resize as nine low-resolution 1x1 products + a bilinear gather (tuning up1_gather; dense_head.py:217-225).  Linear maps
+    behind the last resize as nine low-resolution 1x1 products + a bilinear gather (tuning up1_gather; dense_head.py:217-225), with
+    refinenet1.out_conv (1x1) composed into the nine tap matrices (tuning up1_comp).  Linear maps
     regrouped, so the outputs equal the direct forms' up to where the 16-bit roundings fall (this fixture's weights are the sensitivity-
     maximising preset); the backbone and the camera head are untouched (bit-identical); each form on its own also matches."""
     from hunyuanworld_mirror_amd import _lib
     m, img, out = model_and_out
     L = _lib.lib()
     res = {}
-    for name, kv in (("direct", ((b"tconv", 0), (b"up1_gather", 0))), ("tconv_only", ((b"up1_gather", 0),)), ("up1_only", ((b"tconv", 0),))):
+    for name, kv in (("direct", ((b"tconv", 0), (b"up1_gather", 0))), ("tconv_only", ((b"up1_gather", 0),)), ("up1_only", ((b"tconv", 0),)),
+                     ("out_conv_not_composed", ((b"up1_comp", 0),))):
         for k, v in kv:
             assert L.wm_set_tuning(k, v) == 0
         try:
